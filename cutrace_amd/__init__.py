@@ -1,0 +1,216 @@
+"""cutrace_amd — MI355X-native ray-cast + shading path of jay-tux/cutrace.
+
+The product is native: `libcutrace_amd.so` (HIP kernels behind the C-ABI in
+include/cutrace_amd.h), `libcutrace_host.so` (scene loader / image writers) and the
+`cutrace` CLI.  This package is the thin ctypes plumbing tests and bench.py use.
+"""
+import contextlib
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import Camera, Light, Material, Object, RenderStats, Rows, SceneDesc, Triangle, Vec3  # noqa: F401
+
+ROOT = _lib.ROOT
+
+VAR_AUTO = 0
+VAR_TRI_LDS = 1
+VAR_NO_PREFILTER = 2
+VAR_NO_ANYHIT = 4
+VAR_NO_CLUSTER = 8
+
+
+@contextlib.contextmanager
+def _cwd(path):
+    old = os.getcwd()
+    os.chdir(path)
+    try:
+        yield
+    finally:
+        os.chdir(old)
+
+
+class HostScene:
+    """A scene loaded by the C++ loader (libcutrace_host.so): owns the flat arrays."""
+
+    def __init__(self, handle, status):
+        self._h = handle
+        self.status = status
+
+    @classmethod
+    def load(cls, json_path, cwd=None):
+        """Load a scene JSON. Mesh paths inside it are relative to `cwd` (default: repo root,
+        like the reference which expects to be run from its repository root)."""
+        L = _lib.host_lib()
+        h = C.c_void_p()
+        with _cwd(cwd or ROOT):
+            st = L.ctr_host_scene_load(os.fsencode(json_path), C.byref(h))
+        if not h:
+            raise IOError(f"cannot read scene file {json_path}")
+        return cls(h, st)
+
+    @classmethod
+    def parse(cls, text, cwd=None):
+        L = _lib.host_lib()
+        h = C.c_void_p()
+        with _cwd(cwd or ROOT):
+            st = L.ctr_host_scene_parse(text.encode(), C.byref(h))
+        return cls(h, st)
+
+    @property
+    def ok(self):
+        return self.status == 0
+
+    @property
+    def desc(self):
+        return _lib.host_lib().ctr_host_scene_desc(self._h)
+
+    def set_size(self, w, h):
+        _lib.host_lib().ctr_host_scene_set_size(self._h, w, h)
+
+    def set_material(self, idx, **kw):
+        d = self.desc.contents
+        m = Material()
+        C.memmove(C.byref(m), C.byref(d.materials[idx]), C.sizeof(Material))
+        for k, v in kw.items():
+            if k == "color":
+                m.color = Vec3(*v)
+            else:
+                setattr(m, k, v)
+        st = _lib.host_lib().ctr_host_scene_set_material(self._h, idx, C.byref(m))
+        if st:
+            raise ValueError("bad material index")
+
+    @property
+    def size(self):
+        cam = self.desc.contents.cam
+        return int(cam.w), int(cam.h)
+
+    def close(self):
+        if self._h:
+            _lib.host_lib().ctr_host_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_rows(h, rows=None):
+    """rows: None (whole frame) | (row_begin,row_end) | (row_begin,row_end,block_rows,part,n_parts)"""
+    if rows is None:
+        return Rows(0, h, max(h, 1), 0, 1)
+    if len(rows) == 2:
+        return Rows(rows[0], rows[1], max(h, 1), 0, 1)
+    return Rows(*rows)
+
+
+def rows_count(h, rows):
+    r = make_rows(h, rows)
+    return int(_lib.host_lib().ctr_rows_count(C.byref(r), h))
+
+
+def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids):
+    w, h = scene.size
+    r = make_rows(h, rows)
+    n = rows_count(h, rows)
+    depth = np.empty((n, w), np.float32)
+    color = np.empty((n, w, 3), np.float32)
+    normal = np.empty((n, w, 3), np.float32)
+    hit = np.empty((n, w), np.int64) if want_hit_ids else None
+    counters = (C.c_uint64 * 2)()
+    st = fn(scene.desc, C.c_float(fudge), bounces, C.byref(r), threads, depth.ctypes.data, color.ctypes.data,
+            normal.ctypes.data, hit.ctypes.data if hit is not None else None, counters)
+    if st:
+        raise RuntimeError(f"cpu render failed: {st}")
+    return dict(depth=depth, color=color, normal=normal, hit_id=hit, ray_count=int(counters[0]),
+                alg_bytes=int(counters[1]))
+
+
+def oracle_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
+    """CPU restatement (oracle/ctr_oracle.c).  CHECKER ONLY — tests, smoke(), bench cpu_baseline."""
+    return _cpu_render(_lib.oracle_lib().orc_render, scene, fudge, bounces, rows, threads, hit_ids)
+
+
+def ref_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
+    """The reference's own headers compiled for the host (oracle/_ref).  CHECKER ONLY."""
+    L = _lib.ref_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libcutrace_ref.so not built (needs /root/reference)")
+    return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)
+
+
+class DeviceScene:
+    """A scene uploaded to one GPU through the C-ABI (ctr_scene_create)."""
+
+    def __init__(self, host_scene, device=0):
+        L = _lib.hip_lib()
+        h = C.c_void_p()
+        st = L.ctr_scene_create(host_scene.desc, device, C.byref(h))
+        if st:
+            raise RuntimeError(f"ctr_scene_create failed ({st}): {L.ctr_last_error().decode()}")
+        self._h = h
+        self.device = device
+        self.w, self.h = host_scene.size
+
+    def set_variant(self, bits):
+        st = _lib.hip_lib().ctr_set_variant(self._h, bits)
+        if st:
+            raise RuntimeError(f"ctr_set_variant failed: {_lib.hip_lib().ctr_last_error().decode()}")
+
+    def set_size(self, w, h):
+        st = _lib.hip_lib().ctr_scene_set_size(self._h, w, h)
+        if st:
+            raise RuntimeError("ctr_scene_set_size failed")
+        self.w, self.h = w, h
+
+    def render(self, fudge=1e-3, bounces=5, rows=None):
+        """Host-buffer form (ctr_render): returns numpy buffers + stats."""
+        L = _lib.hip_lib()
+        r = make_rows(self.h, rows)
+        n = rows_count(self.h, rows)
+        depth = np.empty((n, self.w), np.float32)
+        color = np.empty((n, self.w, 3), np.float32)
+        normal = np.empty((n, self.w, 3), np.float32)
+        stats = RenderStats()
+        st = L.ctr_render(self._h, C.c_float(fudge), bounces, C.byref(r), depth.ctypes.data, color.ctypes.data,
+                          normal.ctypes.data, C.byref(stats))
+        if st:
+            raise RuntimeError(f"ctr_render failed ({st}): {L.ctr_last_error().decode()}")
+        return dict(depth=depth, color=color, normal=normal, ray_count=int(stats.ray_count),
+                    kernel_ms=stats.kernel_ms, total_ms=stats.total_ms, max_depth=float(stats.max_depth),
+                    rows=int(stats.rows))
+
+    def render_device(self, d_depth, d_color, d_normal, d_counters=0, stream=0, fudge=1e-3, bounces=5, rows=None):
+        """Device-buffer form (ctr_render_device): raw device pointers, async on `stream`."""
+        L = _lib.hip_lib()
+        r = make_rows(self.h, rows)
+        st = L.ctr_render_device(self._h, C.c_float(fudge), bounces, C.byref(r), d_depth, d_color, d_normal,
+                                 d_counters, stream)
+        if st:
+            raise RuntimeError(f"ctr_render_device failed ({st}): {L.ctr_last_error().decode()}")
+
+    def algorithmic_bytes(self, fudge=1e-3, bounces=5, rows=None):
+        L = _lib.hip_lib()
+        r = make_rows(self.h, rows)
+        b = C.c_uint64()
+        n = C.c_uint64()
+        st = L.ctr_algorithmic_bytes(self._h, C.c_float(fudge), bounces, C.byref(r), C.byref(b), C.byref(n))
+        if st:
+            raise RuntimeError(f"ctr_algorithmic_bytes failed ({st}): {L.ctr_last_error().decode()}")
+        return int(b.value), int(n.value)
+
+    def close(self):
+        if self._h:
+            _lib.hip_lib().ctr_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,176 @@
+"""ctypes view of the C-ABI (include/cutrace_amd.h, include/cutrace_host.h).
+
+Python is plumbing here (tests, bench.py); the product is the C-ABI library and the
+C++ host code.  There is NO Python/CPU fallback for rendering: if libcutrace_amd.so
+is missing or no HIP device is present, rendering raises.
+"""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+    def tup(self):
+        return (self.x, self.y, self.z)
+
+
+class Triangle(C.Structure):
+    _fields_ = [("p1", Vec3), ("p2", Vec3), ("p3", Vec3)]
+
+
+class Object(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("reserved", C.c_uint32), ("mat_idx", C.c_uint64),
+                ("v0", Vec3), ("v1", Vec3), ("v2", Vec3), ("f0", C.c_float),
+                ("tri_begin", C.c_uint64), ("tri_count", C.c_uint64)]
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("v", Vec3), ("color", Vec3)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("color", Vec3), ("specular", C.c_float), ("reflexivity", C.c_float),
+                ("phong_exp", C.c_float), ("transparency", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", Vec3), ("up", Vec3), ("forward", Vec3), ("right", Vec3),
+                ("near_plane", C.c_float), ("far_plane", C.c_float), ("ambient", C.c_float),
+                ("reserved", C.c_uint32), ("w", C.c_uint64), ("h", C.c_uint64)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("objects", C.POINTER(Object)), ("n_objects", C.c_uint64),
+                ("triangles", C.POINTER(Triangle)), ("n_triangles", C.c_uint64),
+                ("lights", C.POINTER(Light)), ("n_lights", C.c_uint64),
+                ("materials", C.POINTER(Material)), ("n_materials", C.c_uint64),
+                ("cam", Camera)]
+
+
+class Rows(C.Structure):
+    _fields_ = [("row_begin", C.c_uint64), ("row_end", C.c_uint64), ("block_rows", C.c_uint64),
+                ("part", C.c_uint32), ("n_parts", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("ray_count", C.c_uint64),
+                ("rows", C.c_uint64), ("max_depth", C.c_float), ("reserved", C.c_uint32)]
+
+
+HOST_SYMBOLS = [
+    "ctr_host_scene_load", "ctr_host_scene_parse", "ctr_host_scene_free", "ctr_host_scene_desc",
+    "ctr_host_scene_set_size", "ctr_host_scene_set_material", "ctr_stl_read", "ctr_stl_write",
+    "ctr_dump_scene", "ctr_dump_schema", "ctr_quantise_depth", "ctr_quantise_normal", "ctr_quantise_color",
+    "ctr_write_jpg", "ctr_write_depth_map", "ctr_write_normal_map", "ctr_write_colorized",
+    "ctr_camera_look_at", "ctr_mesh_bounds", "ctr_rows_count",
+]
+HIP_SYMBOLS = [
+    "ctr_abi_version", "ctr_last_error", "ctr_device_count", "ctr_scene_create", "ctr_scene_destroy",
+    "ctr_scene_size", "ctr_scene_set_size", "ctr_render", "ctr_render_device", "ctr_set_variant",
+    "ctr_algorithmic_bytes",
+]
+
+_host = None
+_hip = None
+_oracle = None
+_ref = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        path = os.path.join(PKG, "libcutrace_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `python -m cutrace_amd.build` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        L.ctr_host_scene_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ctr_host_scene_parse.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ctr_host_scene_free.argtypes = [C.c_void_p]
+        L.ctr_host_scene_desc.argtypes = [C.c_void_p]
+        L.ctr_host_scene_desc.restype = C.POINTER(SceneDesc)
+        L.ctr_host_scene_set_size.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.ctr_host_scene_set_material.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Material)]
+        L.ctr_stl_read.argtypes = [C.c_char_p, C.POINTER(Triangle), C.c_uint64]
+        L.ctr_stl_read.restype = C.c_int64
+        L.ctr_stl_write.argtypes = [C.c_char_p, C.POINTER(Triangle), C.c_uint64]
+        L.ctr_dump_scene.argtypes = [C.POINTER(SceneDesc)]
+        L.ctr_camera_look_at.argtypes = [C.POINTER(Camera), Vec3, Vec3, Vec3]
+        L.ctr_mesh_bounds.argtypes = [C.POINTER(Triangle), C.c_uint64, C.POINTER(Vec3), C.POINTER(Vec3)]
+        L.ctr_rows_count.argtypes = [C.POINTER(Rows), C.c_uint64]
+        L.ctr_rows_count.restype = C.c_uint64
+        for fn in ("ctr_quantise_normal", "ctr_quantise_color"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.ctr_quantise_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
+        L.ctr_write_jpg.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ctr_write_depth_map.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_float]
+        L.ctr_write_normal_map.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.ctr_write_colorized.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        _host = L
+    return _host
+
+
+def hip_lib():
+    """The HIP C-ABI library.  Fails loudly when it is missing: there is no fallback."""
+    global _hip
+    if _hip is None:
+        path = os.path.join(PKG, "libcutrace_amd.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: the HIP extension is not built; refusing to fall back to CPU")
+        # the CLI links both libs; load host first so shared symbols resolve identically
+        host_lib()
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        L.ctr_last_error.restype = C.c_char_p
+        L.ctr_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.ctr_scene_destroy.argtypes = [C.c_void_p]
+        L.ctr_scene_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ctr_scene_set_size.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.ctr_render.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(RenderStats)]
+        L.ctr_render_device.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ctr_set_variant.argtypes = [C.c_void_p, C.c_uint32]
+        L.ctr_algorithmic_bytes.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64)]
+        _hip = L
+    return _hip
+
+
+def _render_sig(fn):
+    fn.argtypes = [C.POINTER(SceneDesc), C.c_float, C.c_int, C.POINTER(Rows), C.c_int, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+
+
+def oracle_lib():
+    """CPU restatement (oracle/ctr_oracle.c). Checker only: tests, smoke(), bench cpu_baseline."""
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ROOT, "oracle", "libctr_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle oracle`")
+        L = C.CDLL(path)
+        _render_sig(L.orc_render)
+        L.orc_look_at.argtypes = [C.POINTER(Camera), Vec3, Vec3, Vec3]
+        L.orc_quantise_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
+        L.orc_quantise_normal.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_quantise_color.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        _oracle = L
+    return _oracle
+
+
+def ref_lib():
+    """The reference's own headers compiled for the host (oracle/_ref). None if not built."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libcutrace_ref.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        _render_sig(L.ref_render)
+        L.ref_look_at.argtypes = [C.POINTER(Camera), Vec3, Vec3, Vec3]
+        _ref = L
+    return _ref

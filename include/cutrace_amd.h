@@ -1,0 +1,201 @@
+/*
+ * cutrace_amd.h — C-ABI of the MI355X-native ray-cast + shading path.
+ *
+ * This is the drop-in boundary for the ONE hot path of jay-tux/cutrace:
+ *
+ *   template <S, size_t bounces = 10, size_t tpb = 256>
+ *   void cutrace::gpu::render(const S &scene, float fudge, float &max,
+ *                             grid<float> &depth_map, grid<vector> &color_map,
+ *                             grid<vector> &normal_map,
+ *                             size_t &render_ms, size_t &total_ms);
+ *                                              (reference inc/kernel.hpp:86-130,
+ *                                               sole caller main.cu:30)
+ *
+ * Everything crossing the boundary is a plain pointer, a size or a POD struct:
+ * no C++ types, no torch types.  The scene is handed over as FLAT host arrays
+ * (ctr_scene_desc) whose elements keep the field order and meaning of the
+ * reference's gpu::schema structs (inc/default_schema.hpp:26-396) and the
+ * reference's variant tag order (inc/default_schema.hpp:920-922):
+ *   objects   triangle=0, mesh=1, plane=2, sphere=3
+ *   lights    sun=0, point=1
+ *   materials phong(solid)=0
+ *
+ * Error convention: the reference's render() returns void and its cudaCheck
+ * macro prints to stderr and continues (inc/cuda.hpp:12-22).  Here every entry
+ * point returns an int status (0 = ok, otherwise a CTR_E_* code or a HIP error
+ * number offset by CTR_E_HIP_BASE); the message is also kept for
+ * ctr_last_error().  Nothing aborts, nothing throws across the ABI.
+ *
+ * The library has NO CPU fallback: if no HIP device / code object is available
+ * the calls fail with a non-zero status.
+ */
+#ifndef CUTRACE_AMD_H
+#define CUTRACE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTR_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define CTR_OK 0
+#define CTR_E_INVALID 1      /* bad argument / malformed scene description   */
+#define CTR_E_NO_DEVICE 2    /* no usable HIP device                          */
+#define CTR_E_IO 3           /* file could not be read / written              */
+#define CTR_E_PARSE 4        /* scene JSON rejected (loader semantics)        */
+#define CTR_E_HIP_BASE 1000  /* 1000 + hipError_t                             */
+
+/* ---- POD vocabulary (mirrors cutrace::vector, inc/vector.hpp:25-28) ----- */
+typedef struct ctr_vec3 { float x, y, z; } ctr_vec3;
+
+/* object tags — reference variant order, inc/default_schema.hpp:920 */
+enum { CTR_OBJ_TRIANGLE = 0, CTR_OBJ_MESH = 1, CTR_OBJ_PLANE = 2, CTR_OBJ_SPHERE = 3 };
+/* light tags — inc/default_schema.hpp:921 */
+enum { CTR_LIGHT_SUN = 0, CTR_LIGHT_POINT = 1 };
+/* material tags — inc/default_schema.hpp:922 */
+enum { CTR_MAT_PHONG = 0 };
+
+/* One mesh triangle: p1,p2,p3 in file order (gpu::schema::triangle,
+ * inc/default_schema.hpp:26-30; mesh triangles all carry the mesh's mat_idx,
+ * inc/default_schema.hpp:536-541, so it is not repeated here). */
+typedef struct ctr_triangle { ctr_vec3 p1, p2, p3; } ctr_triangle;
+
+/* One scene object (the reference's 56-byte gpu_variant of
+ * triangle|mesh|plane|sphere, flattened).
+ *   triangle: v0=p1 v1=p2 v2=p3                    (default_schema.hpp:26-30)
+ *   mesh    : tri_begin/tri_count index ctr_scene_desc.triangles,
+ *             v0=bbox.min v1=bbox.max              (default_schema.hpp:89-92)
+ *   plane   : v0=point v1=normal                   (default_schema.hpp:159-162)
+ *   sphere  : v0=center f0=radius                  (default_schema.hpp:212-215) */
+typedef struct ctr_object {
+  uint32_t type;
+  uint32_t reserved;
+  uint64_t mat_idx;
+  ctr_vec3 v0, v1, v2;
+  float f0;
+  uint64_t tri_begin, tri_count;
+} ctr_object;
+
+/* sun: v=direction; point: v=point            (default_schema.hpp:267-311) */
+typedef struct ctr_light {
+  uint32_t type;
+  ctr_vec3 v;
+  ctr_vec3 color;
+} ctr_light;
+
+/* phong_material                              (default_schema.hpp:319-324) */
+typedef struct ctr_material {
+  uint32_t type;
+  ctr_vec3 color;
+  float specular, reflexivity, phong_exp, transparency;
+} ctr_material;
+
+/* gpu::schema::cam with the basis ALREADY computed on the host, exactly as the
+ * reference does in default_cam::to_gpu → cam::look_at
+ * (default_schema.hpp:370-374, 870-874).  ctr_camera_look_at() below does it. */
+typedef struct ctr_camera {
+  ctr_vec3 pos, up, forward, right;
+  float near_plane, far_plane, ambient;
+  uint32_t reserved;
+  uint64_t w, h;
+} ctr_camera;
+
+/* The flat scene = gpu_scene_{objects,lights,materials,cam}
+ * (inc/gpu_types.hpp:263-274).  All pointers are HOST memory owned by the
+ * caller; ctr_scene_create copies what it needs. */
+typedef struct ctr_scene_desc {
+  const ctr_object *objects;     uint64_t n_objects;
+  const ctr_triangle *triangles; uint64_t n_triangles;
+  const ctr_light *lights;       uint64_t n_lights;
+  const ctr_material *materials; uint64_t n_materials;
+  ctr_camera cam;
+} ctr_scene_desc;
+
+/* Which image rows one call renders.  Rows y with
+ *     row_begin <= y < row_end  and  ((y / block_rows) % n_parts) == part
+ * are rendered, in increasing y, into a COMPACT row-major buffer (the k-th
+ * selected row is local row k).  {0,h,h,0,1} (or all zeros) = whole frame.
+ * Interleaved row blocks are how the frame is tiled over the GPUs of a node:
+ * rank r of n passes {0,h,block_rows,r,n}. */
+typedef struct ctr_rows {
+  uint64_t row_begin, row_end;
+  uint64_t block_rows;
+  uint32_t part, n_parts;
+} ctr_rows;
+
+typedef struct ctr_scene ctr_scene; /* opaque device-resident scene */
+
+/* Per-call statistics (all optional: pass NULL to skip). */
+typedef struct ctr_render_stats {
+  double kernel_ms;     /* HIP-event time of the render kernel (≈ render_ms, kernel.hpp:105-108) */
+  double total_ms;      /* wall time of the call incl. alloc + D2H (≈ total_ms, kernel.hpp:88,126) */
+  uint64_t ray_count;   /* ray_cast invocations of the REFERENCE algorithm for these pixels
+                           (incl. the duplicated primary cast kernel.hpp:52 + shading.hpp:123) */
+  uint64_t rows;        /* rows rendered by this call */
+  float max_depth;      /* largest finite depth, 0 if none (kernel.hpp:120-125) */
+  uint32_t reserved;
+} ctr_render_stats;
+
+/* ---- library ------------------------------------------------------------- */
+int ctr_abi_version(void);
+const char *ctr_last_error(void);
+/* number of visible HIP devices, or a negative status */
+int ctr_device_count(void);
+
+/* ---- host helpers (pure CPU; same arithmetic as the reference's host code) -- */
+/* cam::look_at (default_schema.hpp:370-374): forward, right, up from eye/up/look */
+void ctr_camera_look_at(ctr_camera *cam, ctr_vec3 eye, ctr_vec3 up_hint, ctr_vec3 look);
+/* mesh::bounding_box (default_schema.hpp:573-586) */
+void ctr_mesh_bounds(const ctr_triangle *tris, uint64_t n, ctr_vec3 *bb_min, ctr_vec3 *bb_max);
+/* number of rows selected by a ctr_rows for an image of height h */
+uint64_t ctr_rows_count(const ctr_rows *rows, uint64_t h);
+
+/* ---- scene upload (replaces cpu_to_gpu::convert, inc/cpu_to_gpu.hpp:188-198) -- */
+int ctr_scene_create(const ctr_scene_desc *desc, int device, ctr_scene **out);
+void ctr_scene_destroy(ctr_scene *scene);
+/* image size of the uploaded scene's camera */
+int ctr_scene_size(const ctr_scene *scene, uint64_t *w, uint64_t *h);
+/* change the camera resolution of an uploaded scene (bench/test override; the
+ * reference has no CLI flag for this, main.cu:8-12) */
+int ctr_scene_set_size(ctr_scene *scene, uint64_t w, uint64_t h);
+
+/* ---- THE hot path: replaces gpu::render<S,bounces,tpb> (kernel.hpp:86-130) --
+ * Host-buffer form.  depth: rows*w floats; color3/normal3: rows*w*3 floats in
+ * the AoS layout of grid<vector> (inc/grid.hpp, inc/vector.hpp:25-28), pixel
+ * index local_row*w + x (kernel.hpp:54).  Misses: depth=+inf, normal=0,
+ * color=0 (kernel.hpp:47,50; shading.hpp:119).  Synchronous. */
+int ctr_render(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
+               float *depth, float *color3, float *normal3, ctr_render_stats *stats);
+
+/* Device-buffer form: outputs are DEVICE pointers on the scene's device (e.g.
+ * torch tensors' data_ptr()), the launch is asynchronous on `hip_stream`
+ * (a hipStream_t, NULL = default stream).  No allocation, no sync inside:
+ * graph-capturable.  d_counters: optional device pointer to 2×uint64
+ * {ray_count, max_depth_bits}; the kernel ACCUMULATES into it (atomic add /
+ * atomic max), so zero it before the first launch of a frame. */
+int ctr_render_device(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
+                      void *d_depth, void *d_color3, void *d_normal3,
+                      void *d_counters, void *hip_stream);
+
+/* Kernel variant selection (tuning / ablation; default picks the fastest
+ * variant that is exact for the scene).  Bits: */
+#define CTR_VAR_AUTO 0u
+#define CTR_VAR_TRI_LDS 1u        /* mesh triangles staged in LDS (else wave-uniform scalar loads) */
+#define CTR_VAR_NO_PREFILTER 2u   /* run the exact Cramer test on every triangle */
+#define CTR_VAR_NO_ANYHIT 4u      /* never use the any-hit shadow early-out */
+#define CTR_VAR_NO_CLUSTER 8u     /* ignore triangle-cluster culling */
+int ctr_set_variant(ctr_scene *scene, uint32_t variant_bits);
+
+/* Algorithmic bytes: 56·n_objects per ray_cast + 48·n_tri for
+ * every mesh whose AABB the ray hits + 28 B per pixel, as the reference's flat
+ * traversal streams them; measured by a counting launch of the same kernel. */
+int ctr_algorithmic_bytes(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
+                          uint64_t *bytes, uint64_t *ray_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTRACE_AMD_H */
