@@ -1,0 +1,430 @@
+// ctr_api.cpp — the C-ABI of include/cutrace_amd.h on top of the gfx950 kernel.
+//
+// Replaces the host half of the reference's hot path:
+//   cpu_to_gpu::convert          inc/cpu_to_gpu.hpp:188-198  → ctr_scene_create (one flat upload,
+//                                                               hipMalloc + hipMemcpy, no managed memory)
+//   gpu::render<S,bounces,tpb>   inc/kernel.hpp:86-130       → ctr_render / ctr_render_device
+//
+// Compile with -ffp-contract=off: the ray-independent triangle quantities computed here
+// (a, b, geometric normal) must have the reference's bits.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "cutrace_amd.h"
+#include "scene_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  fprintf(stderr, "cutrace_amd: %s\n", msg.c_str());  // print-and-continue, like cudaCheck (inc/cuda.hpp:12-22)
+  return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+  return fail(CTR_E_HIP_BASE + (int)e, std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")");
+}
+#define HIP_TRY(expr)                                     \
+  do {                                                    \
+    hipError_t _e = (expr);                               \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);     \
+  } while (0)
+
+constexpr float KAPPA = 1.0f / 16384.0f;  // prefilter slack factor 2^-14 (≈1000 ulp), see DESIGN.md
+
+struct f3 { float x, y, z; };
+inline f3 sub(ctr_vec3 a, ctr_vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline f3 cross(f3 a, f3 o) { return {a.y * o.z - a.z * o.y, a.z * o.x - a.x * o.z, a.x * o.y - a.y * o.x}; }
+
+void make_tri(const ctr_vec3 &p1, const ctr_vec3 &p2, const ctr_vec3 &p3, DTri &T, float *gn) {
+  f3 a = sub(p2, p1), b = sub(p2, p3);  // default_schema.hpp:58
+  T.ax = a.x; T.ay = a.y; T.az = a.z;
+  T.bx = b.x; T.by = b.y; T.bz = b.z;
+  T.px = p2.x; T.py = p2.y; T.pz = p2.z;
+  f3 n = cross(a, b);
+  T.nx = n.x; T.ny = n.y; T.nz = n.z;
+  float emax = 0.f;
+  for (float v : {a.x, a.y, a.z, b.x, b.y, b.z}) emax = fmaxf(emax, fabsf(v));
+  T.ke = KAPPA * emax;
+  T.ke2 = KAPPA * emax * emax;
+  T.pad0 = T.pad1 = 0.f;
+  // default_schema.hpp:72: -1.0f * (p2 - p3).cross(p1 - p3).normalized()
+  f3 c = cross(sub(p2, p3), sub(p1, p3));
+  float nrm = sqrtf(c.x * c.x + c.y * c.y + c.z * c.z);
+  float f = 1.0f / nrm;
+  gn[0] = -1.0f * (f * c.x);
+  gn[1] = -1.0f * (f * c.y);
+  gn[2] = -1.0f * (f * c.z);
+  gn[3] = 0.f;
+}
+
+}  // namespace
+
+struct ctr_scene {
+  int device = 0;
+  DObj *d_objs = nullptr;
+  DTri *d_tris = nullptr;
+  float *d_gnorm = nullptr;
+  DLight *d_lights = nullptr;
+  DMat *d_mats = nullptr;
+  uint32_t n_obj = 0, n_tri = 0, n_light = 0, n_mat = 0;
+  bool has_mesh = false;
+  bool all_opaque = true;
+  DCam cam{};
+  uint32_t user_variant = CTR_VAR_AUTO;
+  // cached device outputs for the host-buffer form
+  float *d_depth = nullptr, *d_color = nullptr, *d_normal = nullptr;
+  unsigned long long *d_counters = nullptr;
+  size_t out_px = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::mutex mtx;
+
+  uint32_t kernel_variant(bool count) const {
+    uint32_t kv = 0;
+    if (!(user_variant & CTR_VAR_NO_PREFILTER)) kv |= KV_PREFILTER;
+    // shadow any-hit is result-identical only when every material is exactly opaque
+    // (SURVEY §8(a) row a9); with any transparency the ordered nearest-hit loop is kept
+    if (all_opaque && !(user_variant & CTR_VAR_NO_ANYHIT) && !count) kv |= KV_ANYHIT;
+    if (count) kv |= KV_COUNT;
+    return kv;
+  }
+};
+
+namespace {
+
+int make_rows(const ctr_scene *s, const ctr_rows *rin, DRows &R) {
+  const uint64_t h = s->cam.h;
+  ctr_rows r{0, h, h ? h : 1, 0, 1};
+  if (rin && rin->row_end > rin->row_begin) {
+    r = *rin;
+    if (r.block_rows == 0) r.block_rows = h ? h : 1;
+    if (r.n_parts == 0) { r.n_parts = 1; r.part = 0; }
+    if (r.row_end > h) r.row_end = h;
+  }
+  if (r.part >= r.n_parts) return fail(CTR_E_INVALID, "ctr_rows: part >= n_parts");
+  if (r.n_parts > 1 && (r.row_begin % r.block_rows) != 0)
+    return fail(CTR_E_INVALID, "ctr_rows: row_begin must be a multiple of block_rows when n_parts > 1");
+  R.row_begin = (uint32_t)r.row_begin;
+  R.block_rows = (uint32_t)r.block_rows;
+  R.part = r.part;
+  R.n_parts = r.n_parts;
+  if (r.n_parts <= 1) {
+    R.n_rows = (uint32_t)(r.row_end > r.row_begin ? r.row_end - r.row_begin : 0);
+    R.first_block = 0;
+    R.n_parts = 1;
+    R.part = 0;
+  } else {
+    uint64_t b0 = r.row_begin / r.block_rows;
+    uint64_t first = b0 + ((r.part + r.n_parts - (b0 % r.n_parts)) % r.n_parts);
+    R.first_block = (uint32_t)first;
+    uint64_t n = 0;
+    for (uint64_t b = first; b * r.block_rows < r.row_end; b += r.n_parts) {
+      uint64_t lo = b * r.block_rows, hi = lo + r.block_rows;
+      if (hi > r.row_end) hi = r.row_end;
+      n += hi - lo;
+    }
+    R.n_rows = (uint32_t)n;
+  }
+  return CTR_OK;
+}
+
+void fill_launch(const ctr_scene *s, RenderLaunch &L) {
+  L.objs = s->d_objs;
+  L.tris = s->d_tris;
+  L.gnorm = s->d_gnorm;
+  L.lights = s->d_lights;
+  L.mats = s->d_mats;
+  L.n_obj = s->n_obj;
+  L.n_light = s->n_light;
+  L.n_mat = s->n_mat;
+  L.has_mesh = s->has_mesh ? 1u : 0u;
+  L.cam = s->cam;
+}
+
+int check_args(const ctr_scene *s, int bounces) {
+  if (!s) return fail(CTR_E_INVALID, "null scene");
+  if (bounces < 0 || bounces > CTR_MAX_BOUNCES)
+    return fail(CTR_E_INVALID, "bounces must be in [0," + std::to_string(CTR_MAX_BOUNCES) + "]");
+  if (s->cam.w == 0 || s->cam.h == 0) return fail(CTR_E_INVALID, "camera has zero width or height");
+  return CTR_OK;
+}
+
+int ensure_outputs(ctr_scene *s, size_t px) {
+  if (px <= s->out_px && s->d_depth) return CTR_OK;
+  if (s->d_depth) { (void)hipFree(s->d_depth); (void)hipFree(s->d_color); (void)hipFree(s->d_normal); }
+  s->d_depth = s->d_color = s->d_normal = nullptr;
+  s->out_px = 0;
+  HIP_TRY(hipMalloc((void **)&s->d_depth, sizeof(float) * px));
+  HIP_TRY(hipMalloc((void **)&s->d_color, sizeof(float) * 3 * px));
+  HIP_TRY(hipMalloc((void **)&s->d_normal, sizeof(float) * 3 * px));
+  s->out_px = px;
+  return CTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctr_abi_version(void) { return CTR_ABI_VERSION; }
+const char *ctr_last_error(void) { return g_err.c_str(); }
+
+int ctr_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return -hip_fail(e, "hipGetDeviceCount");
+  return n;
+}
+
+int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
+  if (!d || !out) return fail(CTR_E_INVALID, "ctr_scene_create: null argument");
+  *out = nullptr;
+  // ---- validate the description: the kernel trusts these indices ----
+  if (d->n_objects > 0xFFFFFFFFull || d->n_triangles > 0x7FFFFFFFull || d->cam.w > 0x7FFFFFFFull ||
+      d->cam.h > 0x7FFFFFFFull)
+    return fail(CTR_E_INVALID, "scene too large for 32-bit device indices");
+  if (d->cam.w * d->cam.h > 0x7FFFFFFFull * 2) return fail(CTR_E_INVALID, "image too large");
+  for (uint64_t i = 0; i < d->n_objects; i++) {
+    const ctr_object &o = d->objects[i];
+    if (o.type > CTR_OBJ_SPHERE) return fail(CTR_E_INVALID, "object #" + std::to_string(i) + ": bad type");
+    if (o.mat_idx >= d->n_materials)
+      return fail(CTR_E_INVALID, "object #" + std::to_string(i) + ": material index out of range");
+    if (o.type == CTR_OBJ_MESH && (o.tri_begin > d->n_triangles || o.tri_count > d->n_triangles - o.tri_begin))
+      return fail(CTR_E_INVALID, "object #" + std::to_string(i) + ": triangle range out of bounds");
+  }
+  for (uint64_t i = 0; i < d->n_lights; i++)
+    if (d->lights[i].type > CTR_LIGHT_POINT) return fail(CTR_E_INVALID, "light #" + std::to_string(i) + ": bad type");
+  for (uint64_t i = 0; i < d->n_materials; i++)
+    if (d->materials[i].type != CTR_MAT_PHONG)
+      return fail(CTR_E_INVALID, "material #" + std::to_string(i) + ": bad type");
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(CTR_E_NO_DEVICE, "no HIP device available (and there is no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(CTR_E_INVALID, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  // ---- flatten: mesh triangles first (file order), stand-alone triangles appended ----
+  std::vector<DObj> objs(d->n_objects);
+  std::vector<DTri> tris;
+  std::vector<float> gn;
+  uint64_t n_single = 0;
+  for (uint64_t i = 0; i < d->n_objects; i++)
+    if (d->objects[i].type == CTR_OBJ_TRIANGLE) n_single++;
+  tris.resize(d->n_triangles + n_single);
+  gn.resize(4 * tris.size());
+  for (uint64_t k = 0; k < d->n_triangles; k++)
+    make_tri(d->triangles[k].p1, d->triangles[k].p2, d->triangles[k].p3, tris[k], &gn[4 * k]);
+  uint64_t next_single = d->n_triangles;
+  bool has_mesh = false;
+  for (uint64_t i = 0; i < d->n_objects; i++) {
+    const ctr_object &o = d->objects[i];
+    DObj &O = objs[i];
+    memset(&O, 0, sizeof(O));
+    O.type = o.type;
+    O.mat = (uint32_t)o.mat_idx;
+    switch (o.type) {
+      case CTR_OBJ_TRIANGLE:
+        make_tri(o.v0, o.v1, o.v2, tris[next_single], &gn[4 * next_single]);
+        O.tri_begin = (uint32_t)next_single++;
+        O.tri_count = 1;
+        break;
+      case CTR_OBJ_MESH:
+        has_mesh = true;
+        O.tri_begin = (uint32_t)o.tri_begin;
+        O.tri_count = (uint32_t)o.tri_count;
+        O.f[0] = o.v0.x; O.f[1] = o.v0.y; O.f[2] = o.v0.z;
+        O.f[3] = o.v1.x; O.f[4] = o.v1.y; O.f[5] = o.v1.z;
+        break;
+      case CTR_OBJ_PLANE:
+        O.f[0] = o.v0.x; O.f[1] = o.v0.y; O.f[2] = o.v0.z;
+        O.f[3] = o.v1.x; O.f[4] = o.v1.y; O.f[5] = o.v1.z;
+        break;
+      default:
+        O.f[0] = o.v0.x; O.f[1] = o.v0.y; O.f[2] = o.v0.z;
+        O.f[3] = o.f0;
+        O.f[4] = o.f0 * o.f0;
+        break;
+    }
+  }
+  std::vector<DLight> lights(d->n_lights);
+  for (uint64_t i = 0; i < d->n_lights; i++) {
+    const ctr_light &l = d->lights[i];
+    lights[i] = DLight{l.type, l.v.x, l.v.y, l.v.z, l.color.x, l.color.y, l.color.z, 0.f};
+  }
+  std::vector<DMat> mats(d->n_materials);
+  bool all_opaque = true;
+  for (uint64_t i = 0; i < d->n_materials; i++) {
+    const ctr_material &m = d->materials[i];
+    mats[i] = DMat{m.color.x, m.color.y, m.color.z, m.specular, m.reflexivity, m.phong_exp, m.transparency, 0.f};
+    if (!(m.transparency == 0.0f)) all_opaque = false;
+  }
+
+  auto *s = new ctr_scene();
+  s->device = device;
+  s->n_obj = (uint32_t)objs.size();
+  s->n_tri = (uint32_t)tris.size();
+  s->n_light = (uint32_t)lights.size();
+  s->n_mat = (uint32_t)mats.size();
+  s->has_mesh = has_mesh;
+  s->all_opaque = all_opaque;
+  const ctr_camera &c = d->cam;
+  DCam cam{};
+  cam.pos[0] = c.pos.x; cam.pos[1] = c.pos.y; cam.pos[2] = c.pos.z;
+  cam.up[0] = c.up.x; cam.up[1] = c.up.y; cam.up[2] = c.up.z;
+  cam.forward[0] = c.forward.x; cam.forward[1] = c.forward.y; cam.forward[2] = c.forward.z;
+  cam.right[0] = c.right.x; cam.right[1] = c.right.y; cam.right[2] = c.right.z;
+  cam.ambient = c.ambient;
+  cam.w = (uint32_t)c.w;
+  cam.h = (uint32_t)c.h;
+  s->cam = cam;
+
+  auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+    // never hand the kernel a null base pointer: allocate at least one element's worth
+    hipError_t er = hipMalloc(dst, bytes ? bytes : 64);
+    if (er != hipSuccess) return er;
+    if (bytes) er = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    return er;
+  };
+  hipError_t er;
+  if ((er = upload((void **)&s->d_objs, objs.data(), objs.size() * sizeof(DObj))) != hipSuccess ||
+      (er = upload((void **)&s->d_tris, tris.data(), tris.size() * sizeof(DTri))) != hipSuccess ||
+      (er = upload((void **)&s->d_gnorm, gn.data(), gn.size() * sizeof(float))) != hipSuccess ||
+      (er = upload((void **)&s->d_lights, lights.data(), lights.size() * sizeof(DLight))) != hipSuccess ||
+      (er = upload((void **)&s->d_mats, mats.data(), mats.size() * sizeof(DMat))) != hipSuccess ||
+      (er = hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess ||
+      (er = hipEventCreate(&s->ev0)) != hipSuccess || (er = hipEventCreate(&s->ev1)) != hipSuccess) {
+    ctr_scene_destroy(s);
+    return hip_fail(er, "scene upload");
+  }
+  *out = s;
+  return CTR_OK;
+}
+
+void ctr_scene_destroy(ctr_scene *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  for (void *p : {(void *)s->d_objs, (void *)s->d_tris, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats,
+                  (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters})
+    if (p) (void)hipFree(p);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+}
+
+int ctr_scene_size(const ctr_scene *s, uint64_t *w, uint64_t *h) {
+  if (!s) return fail(CTR_E_INVALID, "null scene");
+  if (w) *w = s->cam.w;
+  if (h) *h = s->cam.h;
+  return CTR_OK;
+}
+
+int ctr_scene_set_size(ctr_scene *s, uint64_t w, uint64_t h) {
+  if (!s || w == 0 || h == 0 || w > 0x7FFFFFFFull || h > 0x7FFFFFFFull) return fail(CTR_E_INVALID, "bad size");
+  s->cam.w = (uint32_t)w;
+  s->cam.h = (uint32_t)h;
+  return CTR_OK;
+}
+
+int ctr_set_variant(ctr_scene *s, uint32_t bits) {
+  if (!s) return fail(CTR_E_INVALID, "null scene");
+  s->user_variant = bits;
+  return CTR_OK;
+}
+
+int ctr_render_device(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, void *d_depth, void *d_color3,
+                      void *d_normal3, void *d_counters, void *hip_stream) {
+  int st = check_args(s, bounces);
+  if (st) return st;
+  if (!d_depth || !d_color3 || !d_normal3) return fail(CTR_E_INVALID, "null output buffer");
+  RenderLaunch L{};
+  fill_launch(s, L);
+  if ((st = make_rows(s, rows, L.rows))) return st;
+  L.fudge = fudge;
+  L.bounces = bounces;
+  L.depth = (float *)d_depth;
+  L.color = (float *)d_color3;
+  L.normal = (float *)d_normal3;
+  L.counters = (unsigned long long *)d_counters;
+  L.variant = s->kernel_variant(false);
+  int e = ctr_launch_render(L, hip_stream);
+  if (e) return hip_fail((hipError_t)e, "render kernel launch");
+  return CTR_OK;
+}
+
+static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,
+                       float *normal3, ctr_render_stats *stats, bool count, unsigned long long *aabb_tris) {
+  auto t0 = std::chrono::high_resolution_clock::now();
+  int st = check_args(s, bounces);
+  if (st) return st;
+  std::lock_guard<std::mutex> lk(s->mtx);
+  HIP_TRY(hipSetDevice(s->device));
+  RenderLaunch L{};
+  fill_launch(s, L);
+  if ((st = make_rows(s, rows, L.rows))) return st;
+  const size_t px = (size_t)L.rows.n_rows * s->cam.w;
+  if ((st = ensure_outputs(s, px ? px : 1))) return st;
+  L.fudge = fudge;
+  L.bounces = bounces;
+  L.depth = s->d_depth;
+  L.color = s->d_color;
+  L.normal = s->d_normal;
+  L.counters = s->d_counters;
+  L.variant = s->kernel_variant(count);
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), nullptr));
+  HIP_TRY(hipEventRecord(s->ev0, nullptr));
+  int e = ctr_launch_render(L, nullptr);
+  if (e) return hip_fail((hipError_t)e, "render kernel launch");
+  HIP_TRY(hipEventRecord(s->ev1, nullptr));
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  // one copy per buffer (the reference does 3·h row-wise copies, kernel.hpp:110-114)
+  if (px) {
+    if (depth) HIP_TRY(hipMemcpy(depth, s->d_depth, sizeof(float) * px, hipMemcpyDeviceToHost));
+    if (color3) HIP_TRY(hipMemcpy(color3, s->d_color, sizeof(float) * 3 * px, hipMemcpyDeviceToHost));
+    if (normal3) HIP_TRY(hipMemcpy(normal3, s->d_normal, sizeof(float) * 3 * px, hipMemcpyDeviceToHost));
+  }
+  unsigned long long cnt[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(cnt, s->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  if (aabb_tris) *aabb_tris = cnt[2];
+  auto t1 = std::chrono::high_resolution_clock::now();
+  if (stats) {
+    stats->kernel_ms = ms;
+    stats->total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    stats->ray_count = cnt[0];
+    stats->rows = L.rows.n_rows;
+    uint32_t bits = (uint32_t)cnt[1];
+    float md;
+    memcpy(&md, &bits, 4);
+    stats->max_depth = md;  // largest finite depth, 0 if none (kernel.hpp:120-125)
+    stats->reserved = 0;
+  }
+  return CTR_OK;
+}
+
+int ctr_render(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,
+               float *normal3, ctr_render_stats *stats) {
+  return render_host(s, fudge, bounces, rows, depth, color3, normal3, stats, false, nullptr);
+}
+
+int ctr_algorithmic_bytes(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, uint64_t *bytes,
+                          uint64_t *ray_count) {
+  ctr_render_stats stt{};
+  unsigned long long aabb = 0;
+  int st = render_host(s, fudge, bounces, rows, nullptr, nullptr, nullptr, &stt, true, &aabb);
+  if (st) return st;
+  // 56·N_obj per ray_cast + 48·N_tri per AABB-hit mesh + 28 B per pixel written
+  if (bytes) *bytes = 56ull * s->n_obj * stt.ray_count + 48ull * aabb + 28ull * stt.rows * s->cam.w;
+  if (ray_count) *ray_count = stt.ray_count;
+  return CTR_OK;
+}
+
+}  // extern "C"

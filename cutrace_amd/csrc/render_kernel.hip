@@ -1,0 +1,533 @@
+// render_kernel.hip — the per-pixel ray-cast + shading kernel for gfx950 (MI355X).
+//
+// What it replaces (reference, file:line):
+//   render_kernel            inc/kernel.hpp:35-60
+//   ray_cast                 inc/ray_cast.hpp:29-55
+//   shadow_intensity/phong/ray_color   inc/shading.hpp:22-154
+//   triangle/mesh/plane/sphere::intersect, lights, material, cam::get_ray
+//                            inc/default_schema.hpp:22-399
+//
+// Design (MI355X-first, not a translation):
+//  * one lane = one pixel, one wave = a TW x TH pixel tile, so the 64 rays of a wave
+//    are spatially coherent; the scene is tiny and read-only, so EVERY scene read in
+//    the hot loops has a wave-uniform address: objects and mesh triangles are fetched
+//    with scalar loads (s_load_dwordx16 = one 64-byte DTri) into SGPRs and feed the
+//    VALU as scalar operands — no VGPRs, no LDS bandwidth, no bank conflicts.
+//  * the recursion of ray_color (template depth `bounces`) becomes an explicit
+//    per-lane state machine: every trip of the outer loop performs exactly ONE
+//    nearest-hit cast for every live lane, whatever that lane needs it for (primary,
+//    reflection, pass-through or a shadow-loop iteration).  The expensive part (the
+//    object/triangle loops) is therefore always executed by a full, converged wave;
+//    only the cheap continuation logic diverges.
+//  * a mesh is skipped for the whole wave when no lane's ray hits its AABB
+//    (ballot), and inside a mesh a conservative FMA prefilter (31 VALU ops) rejects
+//    triangles for the whole wave; only when some lane survives does the wave run
+//    the reference's exact Cramer/determinant test (default_schema.hpp:57-78), in
+//    the reference's operation order, for the surviving lanes.  The prefilter can
+//    only produce false positives, so results are identical to testing everything.
+//  * the duplicated primary cast (kernel.hpp:52 + shading.hpp:123) is done once.
+//
+// Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE correctly
+// rounded on gfx950, so every geometric quantity (depth, hit, normal, which object
+// is hit) is bit-identical to the host-compiled reference.  pow() is evaluated in
+// f64 and rounded once (≤1 ulp from glibc powf), it only feeds the specular colour.
+// Texture coordinates (atan2/asin, uv_for) are never produced: the only material
+// type ignores them (default_schema.hpp:326-340).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "cutrace_amd.h"
+#include "scene_device.h"
+
+#define CADDR __attribute__((address_space(4)))
+
+namespace {
+
+constexpr int TW = 8, TH = 8;           // pixel tile of one wave
+constexpr int WAVES_PER_WG = 4;
+constexpr int WG_THREADS = 64 * WAVES_PER_WG;
+constexpr int MAX_DEPTH = CTR_MAX_BOUNCES + 1;
+
+struct V3 { float x, y, z; };
+
+// ---- inc/vector.hpp, same operation order -------------------------------------
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 vscale(V3 a, float f) { return mk(f * a.x, f * a.y, f * a.z); }
+__device__ __forceinline__ V3 vmul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 vcross(V3 a, V3 o) {
+  return mk(a.y * o.z - a.z * o.y, a.z * o.x - a.x * o.z, a.x * o.y - a.y * o.x);
+}
+__device__ __forceinline__ float vnorm(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 vnormalized(V3 a) { return vscale(a, 1.0f / vnorm(a)); }
+// matrix::determinant, vector.hpp:218-224 (columns c0,c1,c2)
+__device__ __forceinline__ float det3(V3 c0, V3 c1, V3 c2) {
+  float a = c0.x, b = c1.x, c = c2.x, d = c0.y, e = c1.y, f = c2.y, g = c0.z, h = c1.z, i = c2.z;
+  return a * e * i + b * f * g + c * d * h - c * e * g - a * f * h - b * d * i;
+}
+// std::min / std::max as the host-compiled reference binds the unqualified calls
+__device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }
+
+struct Frame {            // one suspended ray_color activation (shading.hpp:116-154)
+  float r, g, b;          // rgb so far
+  float refl, transl;
+  float px, py, pz;       // incoming->start + distance * incoming->dir
+  float dx, dy, dz;       // incoming->dir
+  int bl_stage;           // bounces_left << 2 | stage (1 = waiting for reflection, 2 = for pass-through)
+};
+
+struct KArgs {
+  const CADDR DObj *objs;
+  const CADDR DTri *tris;
+  const CADDR float *gnorm;
+  const CADDR DLight *lights;
+  const CADDR DMat *mats;
+  uint32_t n_obj, n_light;
+  DCam cam;
+  DRows rows;
+  float fudge;
+  int bounces;
+  uint32_t has_mesh;
+};
+
+enum { M_RADIANCE = 0, M_SHADOW = 1, M_DONE = 2 };
+enum { ACT_NONE = 0, ACT_LIGHT = 1, ACT_BOUNCE = 2, ACT_UNWIND = 3 };
+
+template <uint32_t KV>
+__global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__restrict__ depth_out,
+                                                            float *__restrict__ color_out,
+                                                            float *__restrict__ normal_out,
+                                                            unsigned long long *__restrict__ counters) {
+  constexpr bool PREFILTER = (KV & KV_PREFILTER) != 0;
+  constexpr bool ANYHIT = (KV & KV_ANYHIT) != 0;
+  constexpr bool COUNT = (KV & KV_COUNT) != 0;
+
+  const uint32_t w = A.cam.w, h = A.cam.h;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * WAVES_PER_WG) + (threadIdx.x >> 6);
+  const uint32_t tiles_x = (w + TW - 1) / TW;
+  const uint32_t tiles_y = (A.rows.n_rows + TH - 1) / TH;
+  if (wave >= tiles_x * tiles_y) return;  // whole wave exits together
+  const uint32_t tx = wave % tiles_x, ty = wave / tiles_x;
+  const uint32_t x_id = tx * TW + (lane % TW);
+  const uint32_t k_row = ty * TH + (lane / TW);  // local (compact) row
+  const bool in_image = x_id < w && k_row < A.rows.n_rows;
+  // local row -> global image row (interleaved row blocks, see ctr_rows)
+  uint32_t y_id;
+  if (A.rows.n_parts <= 1) y_id = A.rows.row_begin + k_row;
+  else {
+    uint32_t j = k_row / A.rows.block_rows;
+    y_id = (A.rows.first_block + j * A.rows.n_parts) * A.rows.block_rows + (k_row % A.rows.block_rows);
+  }
+  const size_t px_id = (size_t)k_row * w + x_id;  // kernel.hpp:54 on the compact buffer
+
+  // ---- cam::get_ray, default_schema.hpp:376-386 ----
+  V3 ro, rd;
+  {
+    const float fw = (float)w, fh = (float)h;
+    const float aspect = fw / fh;
+    const V3 right = mk(A.cam.right[0], A.cam.right[1], A.cam.right[2]);
+    const V3 up = mk(A.cam.up[0], A.cam.up[1], A.cam.up[2]);
+    const V3 fwd = mk(A.cam.forward[0], A.cam.forward[1], A.cam.forward[2]);
+    V3 x_v = vscale(right, (((float)x_id / fw) - 0.5f) * aspect);
+    V3 y_v = vscale(up, 0.5f - ((float)y_id / fh));
+    ro = mk(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
+    rd = vnormalized(vadd(vadd(x_v, y_v), fwd));
+  }
+  const float ambient = A.cam.ambient;
+
+  // ---- per-lane state machine ----
+  int mode = in_image ? M_RADIANCE : M_DONE;
+  bool first = true;
+  float min_t = A.fudge;
+  int bl = A.bounces;       // bounces left for the current ray_color activation
+  int sp = 0;               // stack pointer
+  Frame stack[MAX_DEPTH];
+  V3 in_o = ro, in_d = rd;  // the radiance ray being shaded ("incoming")
+  V3 hit = mk(0, 0, 0), nn = mk(0, 0, 0), pos = mk(0, 0, 0);
+  V3 fin = mk(0, 0, 0);     // phong accumulator ("final")
+  V3 nd = mk(0, 0, 0);      // normalized direction to the current light
+  float light_dist = 0.f, intensity = 0.f;
+  uint32_t mat_i = 0, li = 0;
+  V3 out_rgb = mk(0, 0, 0);
+  uint32_t n_casts = in_image ? 1u : 0u;  // the duplicated primary cast (kernel.hpp:52) counts too
+  unsigned long long n_aabb_tris = 0;
+  float my_depth = 0.f;
+
+  while (__ballot(mode != M_DONE) != 0ull) {
+    const bool active = mode != M_DONE;
+    const bool shadow_cast = mode == M_SHADOW;
+    n_casts += active ? 1u : 0u;
+
+    // =====================================================================
+    // ray_cast (ray_cast.hpp:29-55): nearest hit of (ro, rd) over all objects
+    // =====================================================================
+    float best = INFINITY;
+    int bobj = -1, btri = -1;
+    bool live = active;  // lanes still searching (any-hit mode retires occluded lanes)
+    V3 rinv = mk(0, 0, 0);
+    float cmax = 0.f;
+    if (A.has_mesh) {
+      rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);  // default_schema.hpp:103
+      cmax = fmaxf(fmaxf(fabsf(rd.x), fabsf(rd.y)), fabsf(rd.z));
+    }
+
+    for (uint32_t i = 0; i < A.n_obj; ++i) {
+      const CADDR DObj &O = A.objs[i];
+      const uint32_t type = O.type;
+      bool ok = false;
+      float cand = INFINITY;
+      int ctri = -1;
+      if (type == CTR_OBJ_MESH) {
+        // ---- mesh::bound_intersects, default_schema.hpp:99-114 (exact, per lane) ----
+        float tmin = 0.0f, tmax = INFINITY;
+        {
+          float t1 = (O.f[0] - ro.x) * rinv.x, t2 = (O.f[3] - ro.x) * rinv.x;
+          tmin = smin(smax(t1, tmin), smax(t2, tmin));
+          tmax = smax(smin(t1, tmax), smin(t2, tmax));
+          t1 = (O.f[1] - ro.y) * rinv.y; t2 = (O.f[4] - ro.y) * rinv.y;
+          tmin = smin(smax(t1, tmin), smax(t2, tmin));
+          tmax = smax(smin(t1, tmax), smin(t2, tmax));
+          t1 = (O.f[2] - ro.z) * rinv.z; t2 = (O.f[5] - ro.z) * rinv.z;
+          tmin = smin(smax(t1, tmin), smax(t2, tmin));
+          tmax = smax(smin(t1, tmax), smin(t2, tmax));
+        }
+        bool bb = live && (tmin <= tmax);
+        if (__ballot(bb) == 0ull) continue;  // no lane of this wave needs the mesh
+        const uint32_t beg = O.tri_begin, cnt = O.tri_count;
+        if (COUNT) n_aabb_tris += bb ? (unsigned long long)cnt : 0ull;
+        // ---- mesh::intersect, default_schema.hpp:125-144: strict-min over file order ----
+        float mt = INFINITY;
+        int mk_ = -1;
+        for (uint32_t k = 0; k < cnt; ++k) {
+          const CADDR DTri &T = A.tris[beg + k];  // wave-uniform: one s_load_dwordx16
+          bool c = bb;
+          if (PREFILTER) {
+            // Conservative reject test.  Same quantities as the exact test
+            // (alpha = det[a b c], A1 = det[d b c], A2 = det[a d c]) evaluated with FMAs
+            // as triple products; every comparison carries a slack E that bounds both this
+            // evaluation's and the reference's rounding, and a
+            // NaN anywhere makes the lane a candidate.
+            const float dx = T.px - ro.x, dy = T.py - ro.y, dz = T.pz - ro.z;
+            const float alpha = __builtin_fmaf(rd.x, T.nx, __builtin_fmaf(rd.y, T.ny, rd.z * T.nz));
+            const float qx = __builtin_fmaf(dy, rd.z, -(dz * rd.y));
+            const float qy = __builtin_fmaf(dz, rd.x, -(dx * rd.z));
+            const float qz = __builtin_fmaf(dx, rd.y, -(dy * rd.x));
+            const float A1n = __builtin_fmaf(T.bx, qx, __builtin_fmaf(T.by, qy, T.bz * qz));  // = -A1
+            const float A2 = __builtin_fmaf(T.ax, qx, __builtin_fmaf(T.ay, qy, T.az * qz));
+            const uint32_t sgn = __float_as_uint(alpha) & 0x80000000u;
+            const float sA1 = __uint_as_float(__float_as_uint(A1n) ^ sgn ^ 0x80000000u);
+            const float sA2 = __uint_as_float(__float_as_uint(A2) ^ sgn);
+            const float absa = fabsf(alpha);
+            const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+            const float E = fmaxf(dmax * T.ke, T.ke2) * cmax;  // kappa * max(dmax,emax) * emax * cmax
+            const bool rej = (sA1 < -E) | (sA2 < -E) | ((sA1 + sA2) > (absa + E));
+            c = bb && (!rej || (absa <= E));
+          }
+          if (__ballot(c) != 0ull) {
+            if (c) {
+              // ---- triangle::intersect, default_schema.hpp:57-78, reference op order ----
+              const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
+              const V3 d = mk(T.px - ro.x, T.py - ro.y, T.pz - ro.z);
+              const float alpha = det3(a, b, rd);
+              const float beta = det3(d, b, rd) / alpha;
+              const float gamma = det3(a, d, rd) / alpha;
+              const float t0 = det3(a, b, d) / alpha;
+              if (beta >= 0 && gamma >= 0 && beta + gamma <= 1 && __builtin_isfinite(t0) && min_t <= t0) {
+                if (t0 < mt) { mt = t0; mk_ = (int)k; }
+                if (ANYHIT) {
+                  // an occluder in (min_t, light_dist): this lane's shadow loop is decided
+                  if (shadow_cast && t0 > min_t && t0 < light_dist) {
+                    bb = false; live = false;
+                    best = t0; bobj = (int)i;
+                  }
+                }
+              }
+            }
+            if (ANYHIT) {
+              if (__ballot(bb) == 0ull) break;
+            }
+          }
+        }
+        ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
+        cand = mt;
+        ctri = (int)beg + mk_;
+      } else if (type == CTR_OBJ_PLANE) {
+        // ---- plane::intersect, default_schema.hpp:189-201 ----
+        const V3 p = mk(O.f[0], O.f[1], O.f[2]), n = mk(O.f[3], O.f[4], O.f[5]);
+        const float t0 = vdot(vsub(p, ro), n) / vdot(rd, n);
+        ok = __builtin_isfinite(t0) && min_t <= t0;
+        cand = t0;
+      } else if (type == CTR_OBJ_SPHERE) {
+        // ---- sphere::intersect, default_schema.hpp:226-251 ----
+        const V3 d = vnormalized(rd), c = mk(O.f[0], O.f[1], O.f[2]);
+        const float R = O.f[3];
+        const V3 ec = vsub(ro, c);
+        const float dec = -vdot(d, ec);
+        const float dd = vdot(d, d);
+        const float sub = dec * dec - dd * (vdot(ec, ec) - R * R);
+        const float sq = sqrtf(sub);
+        const float t0 = (dec - sq) / dd, t1 = (dec + sq) / dd;
+        const bool t0v = __builtin_isfinite(t0) && min_t <= t0, t1v = __builtin_isfinite(t1) && min_t <= t1;
+        ok = t0v || t1v;
+        cand = (t0v && t1v) ? smin(t0, t1) : (t0v ? t0 : t1);
+      } else {
+        // ---- stand-alone triangle, default_schema.hpp:57-78 ----
+        const CADDR DTri &T = A.tris[O.tri_begin];
+        const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
+        const V3 d = mk(T.px - ro.x, T.py - ro.y, T.pz - ro.z);
+        const float alpha = det3(a, b, rd);
+        const float beta = det3(d, b, rd) / alpha;
+        const float gamma = det3(a, d, rd) / alpha;
+        const float t0 = det3(a, b, d) / alpha;
+        ok = beta >= 0 && gamma >= 0 && beta + gamma <= 1 && __builtin_isfinite(t0) && min_t <= t0;
+        cand = t0;
+        ctri = (int)O.tri_begin;
+      }
+      // ray_cast.hpp:43 — first object wins ties (strict <)
+      if (live && ok && cand > min_t && cand < best) {
+        best = cand;
+        bobj = (int)i;
+        btri = ctri;
+      }
+      if (ANYHIT) {
+        if (shadow_cast && live && ok && cand > min_t && cand < light_dist) live = false;
+        if (__ballot(live) == 0ull) break;
+      }
+    }
+    const bool was_hit = bobj >= 0;
+
+    // =====================================================================
+    // continuation: what did this lane cast the ray for?
+    // =====================================================================
+    int act = ACT_NONE;
+    if (mode == M_RADIANCE) {
+      // ---- hit record: hit point, normal (per primitive), material ----
+      V3 normal = mk(0, 0, 0);
+      if (was_hit) {
+        const CADDR DObj &H = A.objs[bobj];
+        mat_i = H.mat;
+        pos = vadd(in_o, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
+        const uint32_t ht = H.type;
+        if (ht == CTR_OBJ_SPHERE) {
+          // default_schema.hpp:245-246: hit uses the NORMALIZED direction
+          hit = vadd(in_o, vscale(vnormalized(in_d), best));
+          normal = vnormalized(vsub(hit, mk(H.f[0], H.f[1], H.f[2])));
+        } else if (ht == CTR_OBJ_PLANE) {
+          hit = pos;
+          normal = mk(H.f[3], H.f[4], H.f[5]);
+        } else {
+          hit = pos;
+          normal = mk(A.gnorm[4 * btri + 0], A.gnorm[4 * btri + 1], A.gnorm[4 * btri + 2]);
+        }
+      }
+      if (first) {
+        // kernel.hpp:55-56 (depth = +inf, normal = 0 on a miss)
+        first = false;
+        my_depth = best;
+        depth_out[px_id] = best;
+        normal_out[3 * px_id + 0] = normal.x;
+        normal_out[3 * px_id + 1] = normal.y;
+        normal_out[3 * px_id + 2] = normal.z;
+      }
+      if (!was_hit) {
+        out_rgb = mk(0.f, 0.f, 0.f);  // shading.hpp:119
+        act = ACT_UNWIND;
+      } else {
+        // phong prologue, shading.hpp:66-76
+        const CADDR DMat &M = A.mats[mat_i];
+        fin = vscale(mk(M.cx, M.cy, M.cz), ambient);
+        nn = vnormalized(normal);
+        li = 0;
+        act = ACT_LIGHT;
+      }
+    } else if (mode == M_SHADOW) {
+      // ---- one iteration of shadow_intensity's loop, shading.hpp:32-42 ----
+      bool done_shadow;
+      float shadow_fac = 0.f;
+      if (was_hit && best < light_dist) {
+        const float trans = A.mats[A.objs[bobj].mat].transparency;
+        intensity += (1.0f - trans);
+        if (intensity >= 1.0f) { shadow_fac = 1.0f; done_shadow = true; }
+        else {
+          min_t = (float)((double)best + 1e-3);  // last_hit + 1e-3 is a double add, shading.hpp:32
+          done_shadow = false;                   // cast again (same ray)
+        }
+      } else {
+        shadow_fac = intensity;
+        done_shadow = true;
+      }
+      if (done_shadow) {
+        if (shadow_fac < 1.0f) {
+          // shading.hpp:86-95
+          const CADDR DMat &M = A.mats[mat_i];
+          const CADDR DLight &Lg = A.lights[li];
+          const V3 diffuse = mk(M.cx, M.cy, M.cz);
+          const V3 specular = vscale(diffuse, M.specular);  // default_schema.hpp:328
+          const V3 color = mk(Lg.cx, Lg.cy, Lg.cz);
+          const float fd = smax(0.0f, vdot(nn, nd));
+          const V3 ld = vmul(diffuse, color);
+          const V3 hv = vnormalized(vadd(vscale(vnormalized(in_d), -1.0f), nd));
+          const float fs = (float)pow((double)smax(0.0f, vdot(nn, hv)), (double)M.phong_exp);
+          const V3 ls = vmul(specular, color);
+          fin = vadd(fin, vscale(vadd(vscale(ld, fd), vscale(ls, fs)), 1 - shadow_fac));
+        }
+        li++;
+        act = ACT_LIGHT;
+      }
+    }
+
+    if (act == ACT_LIGHT) {
+      if (li < A.n_light) {
+        // shading.hpp:79-85: direction/distance to light li, shadow ray from *hit
+        const CADDR DLight &Lg = A.lights[li];
+        V3 direction;
+        float distance;
+        if (Lg.type == CTR_LIGHT_SUN) {  // default_schema.hpp:280-283
+          direction = vscale(mk(Lg.vx, Lg.vy, Lg.vz), -1.0f);
+          distance = INFINITY;
+        } else {                         // default_schema.hpp:305-308
+          const V3 diff = vsub(mk(Lg.vx, Lg.vy, Lg.vz), hit);
+          direction = vnormalized(diff);
+          distance = vnorm(diff);
+        }
+        nd = vnormalized(direction);
+        light_dist = distance * vnorm(direction);
+        ro = hit;
+        rd = nd;
+        intensity = 0.0f;
+        min_t = (float)(0.0 + 1e-3);  // last_hit = 0
+        mode = M_SHADOW;
+      } else {
+        act = ACT_BOUNCE;  // phong returned `fin`
+      }
+    }
+
+    if (act == ACT_BOUNCE) {
+      // shading.hpp:126-150 with rgb = fin
+      const CADDR DMat &M = A.mats[mat_i];
+      const float reflective = M.reflexivity, translucent = M.transparency;
+      const bool do_refl = bl != 0 && (double)reflective >= 1e-6;
+      const bool do_trans = bl != 0 && (double)translucent >= 1e-6;
+      if (do_refl || do_trans) {
+        Frame f;
+        f.r = fin.x; f.g = fin.y; f.b = fin.z;
+        f.refl = reflective; f.transl = translucent;
+        f.px = pos.x; f.py = pos.y; f.pz = pos.z;
+        f.dx = in_d.x; f.dy = in_d.y; f.dz = in_d.z;
+        f.bl_stage = (bl << 2) | (do_refl ? 1 : 2);
+        stack[sp++] = f;
+        in_o = pos;
+        if (do_refl) {
+          // reflect(nd, nn) = nd - (2*(nn.nd))*nn, vector.hpp:204-206
+          const V3 ndir = vnormalized(in_d);
+          in_d = vsub(ndir, vscale(nn, 2.0f * vdot(nn, ndir)));
+        }
+        bl -= 1;
+        ro = in_o; rd = in_d;
+        min_t = A.fudge;
+        mode = M_RADIANCE;
+      } else {
+        out_rgb = fin;
+        act = ACT_UNWIND;
+      }
+    }
+
+    if (act == ACT_UNWIND) {
+      // return `out_rgb` to the suspended callers
+      for (;;) {
+        if (sp == 0) {
+          color_out[3 * px_id + 0] = out_rgb.x;
+          color_out[3 * px_id + 1] = out_rgb.y;
+          color_out[3 * px_id + 2] = out_rgb.z;
+          mode = M_DONE;
+          break;
+        }
+        Frame f = stack[--sp];
+        const int stage = f.bl_stage & 3, fbl = f.bl_stage >> 2;
+        V3 rgb = mk(f.r, f.g, f.b);
+        if (stage == 1) {
+          rgb = vadd(rgb, vscale(out_rgb, f.refl));  // shading.hpp:138
+          if ((double)f.transl >= 1e-6) {
+            f.r = rgb.x; f.g = rgb.y; f.b = rgb.z;
+            f.bl_stage = (fbl << 2) | 2;
+            stack[sp++] = f;
+            in_o = mk(f.px, f.py, f.pz);
+            in_d = mk(f.dx, f.dy, f.dz);
+            bl = fbl - 1;
+            ro = in_o; rd = in_d;
+            min_t = A.fudge;
+            mode = M_RADIANCE;
+            break;
+          }
+          out_rgb = rgb;
+        } else {
+          // shading.hpp:148
+          out_rgb = vadd(vscale(rgb, 1.0f - f.transl), vscale(out_rgb, f.transl));
+        }
+      }
+    }
+  }
+
+  // ---- per-wave reductions -> 2-3 atomics per wave ----
+  if (counters) {
+    unsigned long long c = n_casts;
+    uint32_t dbits = (in_image && __builtin_isfinite(my_depth) && my_depth > 0.f) ? __float_as_uint(my_depth) : 0u;
+    unsigned long long t = n_aabb_tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      c += __shfl_xor(c, off);
+      uint32_t o = (uint32_t)__shfl_xor((int)dbits, off);
+      dbits = o > dbits ? o : dbits;
+      if (COUNT) t += __shfl_xor(t, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&counters[0], c);
+      atomicMax(&counters[1], (unsigned long long)dbits);
+      if (COUNT) atomicAdd(&counters[2], t);
+    }
+  }
+}
+
+template <uint32_t KV>
+int launch(const RenderLaunch &L, hipStream_t stream) {
+  KArgs A;
+  A.objs = (const CADDR DObj *)L.objs;
+  A.tris = (const CADDR DTri *)L.tris;
+  A.gnorm = (const CADDR float *)L.gnorm;
+  A.lights = (const CADDR DLight *)L.lights;
+  A.mats = (const CADDR DMat *)L.mats;
+  A.n_obj = L.n_obj;
+  A.n_light = L.n_light;
+  A.cam = L.cam;
+  A.rows = L.rows;
+  A.fudge = L.fudge;
+  A.bounces = L.bounces;
+  A.has_mesh = L.has_mesh;
+  const uint32_t tiles_x = (L.cam.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
+  const uint64_t waves = (uint64_t)tiles_x * tiles_y;
+  if (waves == 0) return 0;
+  const uint32_t grid = (uint32_t)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
+  hipLaunchKernelGGL(render_kernel<KV>, dim3(grid), dim3(WG_THREADS), 0, stream, A, L.depth, L.color, L.normal,
+                     L.counters);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int ctr_launch_render(const RenderLaunch &L, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (L.variant & 7u) {
+    case 0: return launch<0>(L, s);
+    case 1: return launch<1>(L, s);
+    case 2: return launch<2>(L, s);
+    case 3: return launch<3>(L, s);
+    case 4: return launch<4>(L, s);
+    case 5: return launch<5>(L, s);
+    case 6: return launch<6>(L, s);
+    default: return launch<7>(L, s);
+  }
+}

@@ -1,0 +1,111 @@
+// scene_device.h — HBM layout of the flat scene the render kernel consumes.
+//
+// The reference keeps a 2-level pointer graph in managed memory
+// (scene.objects[i] → gpu_variant → mesh.triangles.buffer, inc/gpu_types.hpp:263-274,
+// inc/cpu_to_gpu.hpp:69-198).  Here the scene is five dense arrays uploaded once:
+//
+//   DObj   objs[n_obj]      64 B records, read wave-uniformly (scalar loads)
+//   DTri   tris[n_tri]      64 B records = one cache line = one s_load_dwordx16;
+//                           all mesh triangles concatenated in FILE ORDER per mesh
+//                           (tie-breaks depend on it), then stand-alone triangles
+//   float4 gnorm[n_tri]     geometric normal of each DTri as the reference computes it on
+//                           a hit; only the winning triangle's is ever fetched
+//   DLight lights[n_light]  32 B
+//   DMat   mats[n_mat]      32 B
+//
+// Ray-independent arithmetic the reference redoes per ray-triangle test is
+// hoisted to upload time WITH THE SAME OPERATIONS (so bits are identical):
+//   a = p2-p1, b = p2-p3            (default_schema.hpp:58)
+//   normal = -1 * normalize((p2-p3) x (p1-p3))   (default_schema.hpp:72)
+// plus prefilter-only data (n = a x b, error scale) whose rounding is irrelevant
+// because the prefilter is conservative and every survivor is re-tested exactly.
+#ifndef CUTRACE_AMD_SCENE_DEVICE_H
+#define CUTRACE_AMD_SCENE_DEVICE_H
+
+#include <stdint.h>
+
+struct DTri {
+  float ax, ay, az;     // a = p2 - p1
+  float bx, by, bz;     // b = p2 - p3
+  float px, py, pz;     // p2
+  float nx, ny, nz;     // a x b (prefilter only)
+  float ke;             // kappa * emax,   emax = max|component of a,b| (prefilter error scale)
+  float ke2;            // kappa * emax^2
+  float pad0, pad1;
+};
+static_assert(sizeof(DTri) == 64, "DTri must be one 64-byte line");
+
+struct DObj {
+  uint32_t type;        // CTR_OBJ_*
+  uint32_t mat;         // material index
+  uint32_t tri_begin;   // mesh: first DTri; triangle: its DTri
+  uint32_t tri_count;   // mesh: number of triangles; triangle: 1
+  // triangle: unused
+  // mesh    : f[0..2] bbox.min, f[3..5] bbox.max
+  // plane   : f[0..2] point,    f[3..5] normal
+  // sphere  : f[0..2] center,   f[3] radius, f[4] radius*radius
+  float f[12];
+};
+static_assert(sizeof(DObj) == 64, "DObj must be 64 bytes");
+
+struct DLight {
+  uint32_t type;        // CTR_LIGHT_*
+  float vx, vy, vz;     // sun: direction; point: position
+  float cx, cy, cz;     // color
+  float pad;
+};
+static_assert(sizeof(DLight) == 32, "DLight must be 32 bytes");
+
+struct DMat {
+  float cx, cy, cz;     // color
+  float specular, reflexivity, phong_exp, transparency;
+  float pad;
+};
+static_assert(sizeof(DMat) == 32, "DMat must be 32 bytes");
+
+struct DCam {
+  float pos[3], up[3], forward[3], right[3];
+  float ambient;
+  uint32_t w, h;
+};
+
+// kernel variant bits (internal; selected from CTR_VAR_* + scene properties)
+enum : uint32_t {
+  KV_PREFILTER = 1u,   // conservative FMA prefilter before the exact Cramer test
+  KV_ANYHIT = 2u,      // shadow casts stop at the first occluder (all-opaque scenes only)
+  KV_COUNT = 4u,       // also accumulate algorithmic-byte counters
+};
+
+struct DRows {
+  uint32_t row_begin;   // first global row of this call's selection
+  uint32_t n_rows;      // number of selected (local) rows
+  uint32_t block_rows;  // interleave block height
+  uint32_t part, n_parts;
+  uint32_t first_block; // index of the first selected block
+};
+
+struct RenderLaunch {
+  const DObj *objs;
+  const DTri *tris;
+  const float *gnorm;   // 4 floats per triangle
+  const DLight *lights;
+  const DMat *mats;
+  uint32_t n_obj, n_light, n_mat;
+  uint32_t has_mesh;
+  DCam cam;
+  DRows rows;
+  float fudge;
+  int bounces;
+  float *depth;
+  float *color;
+  float *normal;
+  unsigned long long *counters;  // [0] ray_count, [1] max-depth bits, [2] AABB-hit triangle count (KV_COUNT)
+  uint32_t variant;
+};
+
+// host-callable launcher implemented in render_kernel.hip; returns a hipError_t as int
+int ctr_launch_render(const RenderLaunch &L, void *stream);
+// maximum `bounces` the kernel supports (explicit per-lane stack depth - 1)
+#define CTR_MAX_BOUNCES 15
+
+#endif

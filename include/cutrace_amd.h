@@ -95,7 +95,7 @@ typedef struct ctr_material {
 
 /* gpu::schema::cam with the basis ALREADY computed on the host, exactly as the
  * reference does in default_cam::to_gpu → cam::look_at
- * (default_schema.hpp:370-374, 870-874).  ctr_camera_look_at() below does it. */
+ * (default_schema.hpp:370-374, 870-874).  ctr_camera_look_at() (cutrace_host.h) does it. */
 typedef struct ctr_camera {
   ctr_vec3 pos, up, forward, right;
   float near_plane, far_plane, ambient;
@@ -144,14 +144,6 @@ int ctr_abi_version(void);
 const char *ctr_last_error(void);
 /* number of visible HIP devices, or a negative status */
 int ctr_device_count(void);
-
-/* ---- host helpers (pure CPU; same arithmetic as the reference's host code) -- */
-/* cam::look_at (default_schema.hpp:370-374): forward, right, up from eye/up/look */
-void ctr_camera_look_at(ctr_camera *cam, ctr_vec3 eye, ctr_vec3 up_hint, ctr_vec3 look);
-/* mesh::bounding_box (default_schema.hpp:573-586) */
-void ctr_mesh_bounds(const ctr_triangle *tris, uint64_t n, ctr_vec3 *bb_min, ctr_vec3 *bb_max);
-/* number of rows selected by a ctr_rows for an image of height h */
-uint64_t ctr_rows_count(const ctr_rows *rows, uint64_t h);
 
 /* ---- scene upload (replaces cpu_to_gpu::convert, inc/cpu_to_gpu.hpp:188-198) -- */
 int ctr_scene_create(const ctr_scene_desc *desc, int device, ctr_scene **out);

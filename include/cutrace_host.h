@@ -15,6 +15,14 @@
 extern "C" {
 #endif
 
+/* ---- host arithmetic feeding the hot path (same operations as the reference's host code) -- */
+/* cam::look_at (default_schema.hpp:370-374): forward, right, up from eye/up/look */
+void ctr_camera_look_at(ctr_camera *cam, ctr_vec3 eye, ctr_vec3 up_hint, ctr_vec3 look);
+/* mesh::bounding_box (default_schema.hpp:573-586) */
+void ctr_mesh_bounds(const ctr_triangle *tris, uint64_t n, ctr_vec3 *bb_min, ctr_vec3 *bb_max);
+/* number of rows selected by a ctr_rows for an image of height h */
+uint64_t ctr_rows_count(const ctr_rows *rows, uint64_t h);
+
 typedef struct ctr_host_scene ctr_host_scene; /* owns the flat arrays behind a ctr_scene_desc */
 
 /* default_schema::load_file (loader.hpp:763-780).  Diagnostics go to stderr with

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE build (oracle/_ref).
+
+Run in the build container only (needs /root/reference to have built
+oracle/_ref/libcutrace_ref.so):   python tests/golden/make_golden.py
+
+What is stored (data only — inputs are the scene files under scene/, outputs are float buffers):
+  small_<scene>_<w>x<h>_b<bounces>.npz   full depth/color/normal/hit_id buffers + ray count
+  full_<scene>_<w>x<h>_b<bounces>.npz    for 1920x1080: double-precision sums of the buffers,
+                                         finite-depth pixel count, ray count, and a fixed
+                                         pseudo-random sample (seed 1234) of 4096 pixels
+The reference build is g++ -O2 -ffp-contract=off of the reference's own headers (oracle/Makefile).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import cutrace_amd as ca  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+THREADS = os.cpu_count() or 8
+
+SMALL = [
+    ("triangle", 20, 20, 5), ("triangle", 128, 128, 5),
+    ("sphere_plane", 96, 54, 5), ("sphere_plane", 96, 54, 2),
+    ("bunny", 96, 54, 5), ("bunny", 64, 36, 0),
+    ("mirror", 96, 54, 5), ("mirror", 96, 54, 8),
+]
+FULL = [("sphere_plane", 1920, 1080, 5), ("mirror", 1920, 1080, 5), ("bunny", 1920, 1080, 5)]
+
+
+def sums(r):
+    d = r["depth"]
+    fin = np.isfinite(d)
+    return dict(
+        sum_color=r["color"].astype(np.float64).reshape(-1, 3).sum(0),
+        sum_normal=r["normal"].astype(np.float64).reshape(-1, 3).sum(0),
+        sum_depth=np.float64(d[fin].astype(np.float64).sum()),
+        n_finite=np.int64(fin.sum()),
+        ray_count=np.int64(r["ray_count"]),
+    )
+
+
+def main():
+    only_small = "--small" in sys.argv
+    for name, w, h, b in SMALL:
+        s = ca.HostScene.load(f"scene/{name}.json")
+        assert s.ok
+        s.set_size(w, h)
+        r = ca.ref_render(s, bounces=b, threads=THREADS)
+        path = os.path.join(OUT, f"small_{name}_{w}x{h}_b{b}.npz")
+        np.savez_compressed(path, depth=r["depth"], color=r["color"], normal=r["normal"], hit_id=r["hit_id"].astype(np.int32),
+                            **sums(r))
+        print("wrote", path, "casts", r["ray_count"])
+    if only_small:
+        return
+    rng = np.random.RandomState(1234)
+    for name, w, h, b in FULL:
+        s = ca.HostScene.load(f"scene/{name}.json")
+        assert s.ok and s.size == (w, h)
+        r = ca.ref_render(s, bounces=b, threads=THREADS)
+        idx = np.sort(rng.choice(w * h, 4096, replace=False)).astype(np.int64)
+        path = os.path.join(OUT, f"full_{name}_{w}x{h}_b{b}.npz")
+        np.savez_compressed(path, sample_idx=idx, depth=r["depth"].reshape(-1)[idx], color=r["color"].reshape(-1, 3)[idx],
+                            normal=r["normal"].reshape(-1, 3)[idx], hit_id=r["hit_id"].reshape(-1)[idx].astype(np.int32),
+                            **sums(r))
+        print("wrote", path, "casts", r["ray_count"], sums(r))
+
+
+if __name__ == "__main__":
+    main()
