@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s (primary + secondary) and frame ms on scene/bunny.json @1920x1080.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched by torch.distributed.run, one rank per GPU (RCCL).  A *step* is one pass of
+  the hot path over one batch: N frames of the workload, every frame row-tiled over the N ranks
+  (interleaved 8-row blocks), finished by ONE gather of the packed buffers to rank 0, which
+  re-interleaves them into the final row-major frames.  Per-GPU work is one frame-equivalent at
+  every N  ->  "scaling": "weak".  (--scaling strong keeps one frame per step.)
+
+  value   = rays of the reference algorithm for all frames of the K timed steps / wall seconds
+            (max over ranks), in Mrays/s; inputs (the uploaded scene) are resident in HBM.
+  rays    = ray_cast invocations the REFERENCE algorithm performs (incl. its duplicated primary
+            cast), the fixed numerator SURVEY.md §8(d) defines; counted by the kernel itself and
+            equal to the oracle's count (64 278 888 for the default workload; tested).
+  roofline= algorithmic bytes per launch (56 B x objects per ray_cast + 48 B x
+            triangles of every mesh whose AABB the ray hits + 28 B per pixel) / mean kernel
+            duration from HIP events on the launch stream, against 8 TB/s HBM.  NOTE the kernel
+            is VALU-bound, not HBM-bound: the scene (<1 MB) is served from scalar cache/L2, so
+            the algorithmic figure exceeds what HBM actually carries.
+  cpu_baseline = the CPU checker (oracle/_ref = the reference's own headers built for the host
+            when present, else the plain-C port) on a bounded row sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--scene", default="scene/bunny.json")
+    p.add_argument("--width", type=int, default=0)
+    p.add_argument("--height", type=int, default=0)
+    p.add_argument("--bounces", type=int, default=5)
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    p.add_argument("--variant", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-div", type=int, default=0, help="CPU baseline renders 1/div of the row blocks (0=auto)")
+    p.add_argument("--traffic-json", default="", help="optional JSON with PMC-derived HBM bytes per launch")
+    return p.parse_args()
+
+
+def cpu_baseline(ca, host_scene, bounces, div):
+    """Bounded CPU sample: every `div`-th 8-row block of the same frame, all host threads."""
+    from cutrace_amd import _lib
+    w, h = host_scene.size
+    threads = min(os.cpu_count() or 1, 64)
+    use_ref = _lib.ref_lib() is not None
+    fn = ca.ref_render if use_ref else ca.oracle_render
+    if div <= 0:
+        # aim at ~10-30 s: ~0.14 Mrays/s per thread measured for this workload
+        est_full = 64.3e6 * (w * h / 2073600.0) / (0.14e6 * threads)
+        div = max(1, int(round(est_full / 15.0)))
+    rows = (0, h, 8, 0, div)
+    t0 = time.perf_counter()
+    r = fn(host_scene, bounces=bounces, rows=rows, threads=threads, hit_ids=False)
+    dt = time.perf_counter() - t0
+    return {
+        "value": r["ray_count"] / dt / 1e6, "unit": "Mrays/s", "cores": threads,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"every {div}th 8-row block of the {w}x{h} frame ({r['depth'].shape[0]} rows, "
+                  f"{r['ray_count']} rays) in {dt:.2f} s",
+        "seconds": dt,
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import cutrace_amd as ca
+    from cutrace_amd.tiling import FrameTiler
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    hs = ca.HostScene.load(args.scene)
+    assert hs.ok, "scene failed to load"
+    if args.width and args.height:
+        hs.set_size(args.width, args.height)
+    w, h = hs.size
+    ds = ca.DeviceScene(hs, device=local_rank)  # raises when the HIP library is missing
+    if args.variant:
+        ds.set_variant(args.variant)
+    frames = world if args.scaling == "weak" else 1
+    tiler = FrameTiler(w, h, frames, rank, world, dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def render_step(events=None):
+        for f in range(frames):
+            d, c, n = tiler.views(f)
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            ds.render_device(d.data_ptr(), c.data_ptr(), n.data_ptr(), counters.data_ptr(), stream.cuda_stream,
+                             fudge=1e-3, bounces=args.bounces, rows=tiler.rows)
+            if events is not None:
+                e1.record(stream)
+                events.append((e0, e1))
+        tiler.gather()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # rays per step for this rank (counting launch, untimed)
+    counters.zero_()
+    render_step()
+    torch.cuda.synchronize()
+    rays_rank_step = int(counters[0].item())
+    for _ in range(max(0, args.warmup - 1)):
+        render_step()
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        render_step(events)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    kern_ms = [a.elapsed_time(b) for a, b in events]
+    t = torch.tensor([dt, float(rays_rank_step), sum(kern_ms) / max(1, len(kern_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, rays_step, kern_avg = float(tmax[0]), float(tsum[1]), float(tsum[2]) / world
+    else:
+        dt_max, rays_step, kern_avg = dt, float(rays_rank_step), float(t[2])
+
+    if rank == 0:
+        total_rays = rays_step * args.steps
+        value = total_rays / dt_max / 1e6
+        # ---- roofline of the dominant (only) kernel, per launch ----
+        alg_bytes, alg_rays = ds.algorithmic_bytes(bounces=args.bounces, rows=tiler.rows)
+        achieved = alg_bytes / (kern_avg * 1e-3) / 1e9 if kern_avg > 0 else 0.0
+        traffic = None
+        if args.traffic_json and os.path.exists(args.traffic_json):
+            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "render_kernel",
+                "kernel_ms_avg": kern_avg, "algorithmic_bytes_per_launch": alg_bytes,
+                "rays_per_launch": alg_rays,
+                "note": "VALU-bound kernel: scene is cache-resident, algorithmic bytes are what the "
+                        "reference's flat traversal streams per ray, not HBM traffic"}
+        out = {
+            "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
+                                   f"{frames} frame(s)/step row-tiled over {world} GPU(s), gather to rank 0",
+                       "frames_per_step": frames, "rays_per_step": rays_step,
+                       "frame_ms": dt_max / args.steps * 1e3 / frames,
+                       "unique_mrays_per_s": (rays_step - frames * w * h) * args.steps / dt_max / 1e6},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ca, hs, args.bounces, args.cpu_sample_div)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

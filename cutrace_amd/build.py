@@ -23,7 +23,7 @@ HIP_LIB = os.path.join(PKG, "libcutrace_amd.so")
 CLI = os.path.join(PKG, "cutrace")
 
 HOST_SRCS = [os.path.join(HOST, "scene_host.cpp"), os.path.join(HOST, "images.cpp")]
-HIP_SRCS = [os.path.join(CSRC, "render_kernel.hip"), os.path.join(CSRC, "ctr_api.cpp")]
+HIP_SRCS = [os.path.join(CSRC, "render_kernel.hip"), os.path.join(CSRC, "ctr_api.cpp"), os.path.join(CSRC, "bvh.cpp")]
 CLI_SRCS = [os.path.join(HOST, "main.cpp")]
 
 HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I" + INC]

@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "bvh.h"
 #include "cutrace_amd.h"
 #include "scene_device.h"
 
@@ -44,7 +45,9 @@ struct f3 { float x, y, z; };
 inline f3 sub(ctr_vec3 a, ctr_vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline f3 cross(f3 a, f3 o) { return {a.y * o.z - a.z * o.y, a.z * o.x - a.x * o.z, a.x * o.y - a.y * o.x}; }
 
-void make_tri(const ctr_vec3 &p1, const ctr_vec3 &p2, const ctr_vec3 &p3, DTri &T, float *gn) {
+constexpr uint32_t BVH_LEAF = 4;          // triangles per BVH leaf
+
+void make_tri(const ctr_vec3 &p1, const ctr_vec3 &p2, const ctr_vec3 &p3, uint32_t orig, DTri &T, float *gn) {
   f3 a = sub(p2, p1), b = sub(p2, p3);  // default_schema.hpp:58
   T.ax = a.x; T.ay = a.y; T.az = a.z;
   T.bx = b.x; T.by = b.y; T.bz = b.z;
@@ -55,7 +58,8 @@ void make_tri(const ctr_vec3 &p1, const ctr_vec3 &p2, const ctr_vec3 &p3, DTri &
   for (float v : {a.x, a.y, a.z, b.x, b.y, b.z}) emax = fmaxf(emax, fabsf(v));
   T.ke = KAPPA * emax;
   T.ke2 = KAPPA * emax * emax;
-  T.pad0 = T.pad1 = 0.f;
+  T.orig = orig;
+  T.pad1 = 0.f;
   // default_schema.hpp:72: -1.0f * (p2 - p3).cross(p1 - p3).normalized()
   f3 c = cross(sub(p2, p3), sub(p1, p3));
   float nrm = sqrtf(c.x * c.x + c.y * c.y + c.z * c.z);
@@ -72,6 +76,7 @@ struct ctr_scene {
   int device = 0;
   DObj *d_objs = nullptr;
   DTri *d_tris = nullptr;
+  DNode *d_nodes = nullptr;
   float *d_gnorm = nullptr;
   DLight *d_lights = nullptr;
   DMat *d_mats = nullptr;
@@ -93,7 +98,8 @@ struct ctr_scene {
     // shadow any-hit is result-identical only when every material is exactly opaque
     // (SURVEY §8(a) row a9); with any transparency the ordered nearest-hit loop is kept
     if (all_opaque && !(user_variant & CTR_VAR_NO_ANYHIT) && !count) kv |= KV_ANYHIT;
-    if (count) kv |= KV_COUNT;
+    if (!(user_variant & CTR_VAR_NO_CLUSTER) && !count) kv |= KV_BVH;
+    if (count) kv = KV_PREFILTER | KV_COUNT;  // the counting launch walks like the reference
     return kv;
   }
 };
@@ -139,6 +145,7 @@ int make_rows(const ctr_scene *s, const ctr_rows *rin, DRows &R) {
 void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.objs = s->d_objs;
   L.tris = s->d_tris;
+  L.nodes = s->d_nodes;
   L.gnorm = s->d_gnorm;
   L.lights = s->d_lights;
   L.mats = s->d_mats;
@@ -211,18 +218,13 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   if (device < 0 || device >= ndev) return fail(CTR_E_INVALID, "device index out of range");
   HIP_TRY(hipSetDevice(device));
 
-  // ---- flatten: mesh triangles first (file order), stand-alone triangles appended ----
+  // ---- flatten: per mesh a BVH + its triangles in leaf order (each keeps its file index for
+  //      tie-breaks), stand-alone triangles appended ----
   std::vector<DObj> objs(d->n_objects);
   std::vector<DTri> tris;
+  std::vector<DNode> nodes;
   std::vector<float> gn;
-  uint64_t n_single = 0;
-  for (uint64_t i = 0; i < d->n_objects; i++)
-    if (d->objects[i].type == CTR_OBJ_TRIANGLE) n_single++;
-  tris.resize(d->n_triangles + n_single);
-  gn.resize(4 * tris.size());
-  for (uint64_t k = 0; k < d->n_triangles; k++)
-    make_tri(d->triangles[k].p1, d->triangles[k].p2, d->triangles[k].p3, tris[k], &gn[4 * k]);
-  uint64_t next_single = d->n_triangles;
+  tris.reserve(d->n_triangles + d->n_objects);
   bool has_mesh = false;
   for (uint64_t i = 0; i < d->n_objects; i++) {
     const ctr_object &o = d->objects[i];
@@ -231,18 +233,50 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     O.type = o.type;
     O.mat = (uint32_t)o.mat_idx;
     switch (o.type) {
-      case CTR_OBJ_TRIANGLE:
-        make_tri(o.v0, o.v1, o.v2, tris[next_single], &gn[4 * next_single]);
-        O.tri_begin = (uint32_t)next_single++;
+      case CTR_OBJ_TRIANGLE: {
+        O.tri_begin = (uint32_t)tris.size();
         O.tri_count = 1;
+        tris.emplace_back();
+        gn.resize(4 * tris.size());
+        make_tri(o.v0, o.v1, o.v2, 0, tris.back(), &gn[4 * (tris.size() - 1)]);
         break;
-      case CTR_OBJ_MESH:
+      }
+      case CTR_OBJ_MESH: {
         has_mesh = true;
-        O.tri_begin = (uint32_t)o.tri_begin;
-        O.tri_count = (uint32_t)o.tri_count;
+        const ctr_triangle *src = d->triangles + o.tri_begin;
+        const uint32_t n = (uint32_t)o.tri_count;
+        std::vector<BvhInput> prims(n);
+        for (uint32_t k = 0; k < n; k++) {
+          const ctr_vec3 *v[3] = {&src[k].p1, &src[k].p2, &src[k].p3};
+          BvhInput &b = prims[k];
+          for (int a = 0; a < 3; a++) {
+            const float c0 = (&v[0]->x)[a], c1 = (&v[1]->x)[a], c2 = (&v[2]->x)[a];
+            b.mn[a] = fminf(c0, fminf(c1, c2));
+            b.mx[a] = fmaxf(c0, fmaxf(c1, c2));
+            b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
+          }
+        }
+        std::vector<DNode> mnodes;
+        std::vector<uint32_t> order;
+        bvh_build(prims, BVH_LEAF, mnodes, order);
+        O.tri_begin = (uint32_t)tris.size();
+        O.tri_count = n;
+        O.node_begin = (uint32_t)nodes.size();
+        O.node_count = (uint32_t)mnodes.size();
+        for (DNode &nd : mnodes) {
+          if (nd.count) nd.first += O.tri_begin;  // absolute triangle index
+          nodes.push_back(nd);                    // skip stays relative to the mesh's first node
+        }
+        tris.resize(tris.size() + n);
+        gn.resize(4 * tris.size());
+        for (uint32_t k = 0; k < n; k++) {
+          const ctr_triangle &t = src[order[k]];
+          make_tri(t.p1, t.p2, t.p3, order[k], tris[O.tri_begin + k], &gn[4 * (O.tri_begin + k)]);
+        }
         O.f[0] = o.v0.x; O.f[1] = o.v0.y; O.f[2] = o.v0.z;
         O.f[3] = o.v1.x; O.f[4] = o.v1.y; O.f[5] = o.v1.z;
         break;
+      }
       case CTR_OBJ_PLANE:
         O.f[0] = o.v0.x; O.f[1] = o.v0.y; O.f[2] = o.v0.z;
         O.f[3] = o.v1.x; O.f[4] = o.v1.y; O.f[5] = o.v1.z;
@@ -296,6 +330,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   hipError_t er;
   if ((er = upload((void **)&s->d_objs, objs.data(), objs.size() * sizeof(DObj))) != hipSuccess ||
       (er = upload((void **)&s->d_tris, tris.data(), tris.size() * sizeof(DTri))) != hipSuccess ||
+      (er = upload((void **)&s->d_nodes, nodes.data(), nodes.size() * sizeof(DNode))) != hipSuccess ||
       (er = upload((void **)&s->d_gnorm, gn.data(), gn.size() * sizeof(float))) != hipSuccess ||
       (er = upload((void **)&s->d_lights, lights.data(), lights.size() * sizeof(DLight))) != hipSuccess ||
       (er = upload((void **)&s->d_mats, mats.data(), mats.size() * sizeof(DMat))) != hipSuccess ||
@@ -311,7 +346,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
 void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void *p : {(void *)s->d_objs, (void *)s->d_tris, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats,
+  for (void *p : {(void *)s->d_objs, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats,
                   (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters})
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);

@@ -39,8 +39,10 @@
 
 #include "cutrace_amd.h"
 #include "scene_device.h"
+#include "bvh.h"
 
 #define CADDR __attribute__((address_space(4)))
+#define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 
 namespace {
 
@@ -83,6 +85,7 @@ struct Frame {            // one suspended ray_color activation (shading.hpp:116
 struct KArgs {
   const CADDR DObj *objs;
   const CADDR DTri *tris;
+  const CADDR DNode *nodes;
   const CADDR float *gnorm;
   const CADDR DLight *lights;
   const CADDR DMat *mats;
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
   constexpr bool PREFILTER = (KV & KV_PREFILTER) != 0;
   constexpr bool ANYHIT = (KV & KV_ANYHIT) != 0;
   constexpr bool COUNT = (KV & KV_COUNT) != 0;
+  constexpr bool BVH = (KV & KV_BVH) != 0;
 
   const uint32_t w = A.cam.w, h = A.cam.h;
   const uint32_t lane = threadIdx.x & 63u;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
   unsigned long long n_aabb_tris = 0;
   float my_depth = 0.f;
 
-  while (__ballot(mode != M_DONE) != 0ull) {
+  while (BALLOT(mode != M_DONE) != 0ull) {
     const bool active = mode != M_DONE;
     const bool shadow_cast = mode == M_SHADOW;
     n_casts += active ? 1u : 0u;
@@ -197,15 +201,18 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
           tmax = smax(smin(t1, tmax), smin(t2, tmax));
         }
         bool bb = live && (tmin <= tmax);
-        if (__ballot(bb) == 0ull) continue;  // no lane of this wave needs the mesh
+        if (BALLOT(bb) == 0ull) continue;  // no lane of this wave needs the mesh
         const uint32_t beg = O.tri_begin, cnt = O.tri_count;
         if (COUNT) n_aabb_tris += bb ? (unsigned long long)cnt : 0ull;
-        // ---- mesh::intersect, default_schema.hpp:125-144: strict-min over file order ----
+        // ---- mesh::intersect, default_schema.hpp:125-144: smallest valid t, FIRST triangle in
+        //      file order on ties (strict < over file order)  ==  lexicographic min of (t, orig) ----
         float mt = INFINITY;
         int mk_ = -1;
-        for (uint32_t k = 0; k < cnt; ++k) {
-          const CADDR DTri &T = A.tris[beg + k];  // wave-uniform: one s_load_dwordx16
-          bool c = bb;
+        uint32_t morig = 0xFFFFFFFFu;
+
+        // one triangle against the lanes in `lanes` (wave-uniform T: SGPR operands)
+        auto tri_test = [&](const CADDR DTri &T, uint32_t tri_index, bool lanes) {
+          bool c = lanes;
           if (PREFILTER) {
             // Conservative reject test.  Same quantities as the exact test
             // (alpha = det[a b c], A1 = det[d b c], A2 = det[a d c]) evaluated with FMAs
@@ -226,9 +233,9 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
             const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
             const float E = fmaxf(dmax * T.ke, T.ke2) * cmax;  // kappa * max(dmax,emax) * emax * cmax
             const bool rej = (sA1 < -E) | (sA2 < -E) | ((sA1 + sA2) > (absa + E));
-            c = bb && (!rej || (absa <= E));
+            c = lanes && (!rej || (absa <= E));
           }
-          if (__ballot(c) != 0ull) {
+          if (BALLOT(c) != 0ull) {
             if (c) {
               // ---- triangle::intersect, default_schema.hpp:57-78, reference op order ----
               const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
@@ -238,7 +245,8 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
               const float gamma = det3(a, d, rd) / alpha;
               const float t0 = det3(a, b, d) / alpha;
               if (beta >= 0 && gamma >= 0 && beta + gamma <= 1 && __builtin_isfinite(t0) && min_t <= t0) {
-                if (t0 < mt) { mt = t0; mk_ = (int)k; }
+                const uint32_t orig = T.orig;
+                if (t0 < mt || (t0 == mt && orig < morig)) { mt = t0; mk_ = (int)tri_index; morig = orig; }
                 if (ANYHIT) {
                   // an occluder in (min_t, light_dist): this lane's shadow loop is decided
                   if (shadow_cast && t0 > min_t && t0 < light_dist) {
@@ -248,14 +256,55 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
                 }
               }
             }
+          }
+        };
+
+        if (BVH) {
+          // Stackless walk of the mesh's pre-order BVH, the whole wave together: a subtree is
+          // entered when ANY lane's ray touches its box.  The box test is conservative: boxes are
+          // widened by m = 2^-15 x (largest |coordinate difference| between the ray origin and the
+          // mesh), applied in t-space as a slack of 2*m*max|1/dir|.
+          const float gx = fmaxf(fabsf(O.f[0] - ro.x), fabsf(O.f[3] - ro.x));
+          const float gy = fmaxf(fabsf(O.f[1] - ro.y), fabsf(O.f[4] - ro.y));
+          const float gz = fmaxf(fabsf(O.f[2] - ro.z), fabsf(O.f[5] - ro.z));
+          const float slack = (fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f) *
+                              fmaxf(fmaxf(fabsf(rinv.x), fabsf(rinv.y)), fabsf(rinv.z));
+          const CADDR DNode *nodes = A.nodes + O.node_begin;
+          const uint32_t n_nodes = O.node_count;
+          uint32_t ni = 0;
+          while (ni < n_nodes) {
+            const CADDR DNode &N = nodes[ni];
+            const float t1x = (N.mnx - ro.x) * rinv.x, t2x = (N.mxx - ro.x) * rinv.x;
+            const float t1y = (N.mny - ro.y) * rinv.y, t2y = (N.mxy - ro.y) * rinv.y;
+            const float t1z = (N.mnz - ro.z) * rinv.z, t2z = (N.mxz - ro.z) * rinv.z;
+            const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+            const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+            // reject only on a definite miss (NaN compares false -> the node is entered)
+            const float far_lim = (ANYHIT && shadow_cast) ? light_dist : fminf(best, mt);
+            const bool miss = ((lo - slack) > hi) | ((hi + slack) < min_t) | ((lo - slack) > far_lim);
+            const bool hnode = bb && !miss;
+            if (BALLOT(hnode) != 0ull) {
+              const uint32_t cnt_l = N.count, first = N.first;
+              for (uint32_t k = 0; k < cnt_l; ++k) tri_test(A.tris[first + k], first + k, hnode);
+              ni += 1;
+              if (ANYHIT) {
+                if (BALLOT(bb) == 0ull) break;
+              }
+            } else {
+              ni = N.skip;
+            }
+          }
+        } else {
+          for (uint32_t k = 0; k < cnt; ++k) {
+            tri_test(A.tris[beg + k], beg + k, bb);  // wave-uniform: one s_load_dwordx16
             if (ANYHIT) {
-              if (__ballot(bb) == 0ull) break;
+              if (BALLOT(bb) == 0ull) break;
             }
           }
         }
         ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
         cand = mt;
-        ctri = (int)beg + mk_;
+        ctri = mk_;
       } else if (type == CTR_OBJ_PLANE) {
         // ---- plane::intersect, default_schema.hpp:189-201 ----
         const V3 p = mk(O.f[0], O.f[1], O.f[2]), n = mk(O.f[3], O.f[4], O.f[5]);
@@ -296,7 +345,7 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
       }
       if (ANYHIT) {
         if (shadow_cast && live && ok && cand > min_t && cand < light_dist) live = false;
-        if (__ballot(live) == 0ull) break;
+        if (BALLOT(live) == 0ull) break;
       }
     }
     const bool was_hit = bobj >= 0;
@@ -497,6 +546,7 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   KArgs A;
   A.objs = (const CADDR DObj *)L.objs;
   A.tris = (const CADDR DTri *)L.tris;
+  A.nodes = (const CADDR DNode *)L.nodes;
   A.gnorm = (const CADDR float *)L.gnorm;
   A.lights = (const CADDR DLight *)L.lights;
   A.mats = (const CADDR DMat *)L.mats;
@@ -520,14 +570,15 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
 
 int ctr_launch_render(const RenderLaunch &L, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  switch (L.variant & 7u) {
+  if (L.variant & KV_COUNT) return launch<KV_PREFILTER | KV_COUNT>(L, s);
+  switch (L.variant & (KV_PREFILTER | KV_ANYHIT | KV_BVH)) {
     case 0: return launch<0>(L, s);
-    case 1: return launch<1>(L, s);
-    case 2: return launch<2>(L, s);
-    case 3: return launch<3>(L, s);
-    case 4: return launch<4>(L, s);
-    case 5: return launch<5>(L, s);
-    case 6: return launch<6>(L, s);
-    default: return launch<7>(L, s);
+    case KV_PREFILTER: return launch<KV_PREFILTER>(L, s);
+    case KV_ANYHIT: return launch<KV_ANYHIT>(L, s);
+    case KV_PREFILTER | KV_ANYHIT: return launch<KV_PREFILTER | KV_ANYHIT>(L, s);
+    case KV_BVH: return launch<KV_BVH>(L, s);
+    case KV_BVH | KV_PREFILTER: return launch<KV_BVH | KV_PREFILTER>(L, s);
+    case KV_BVH | KV_ANYHIT: return launch<KV_BVH | KV_ANYHIT>(L, s);
+    default: return launch<KV_BVH | KV_PREFILTER | KV_ANYHIT>(L, s);
   }
 }

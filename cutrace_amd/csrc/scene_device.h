@@ -6,8 +6,10 @@
 //
 //   DObj   objs[n_obj]      64 B records, read wave-uniformly (scalar loads)
 //   DTri   tris[n_tri]      64 B records = one cache line = one s_load_dwordx16;
-//                           all mesh triangles concatenated in FILE ORDER per mesh
-//                           (tie-breaks depend on it), then stand-alone triangles
+//                           per mesh in BVH-leaf order, each carrying its ORIGINAL file
+//                           index (ties on t are broken by it, so results do not depend
+//                           on the order); then stand-alone triangles
+//   DNode  nodes[n_node]    64 B records, per-mesh BVH in pre-order with skip links (bvh.h)
 //   float4 gnorm[n_tri]     geometric normal of each DTri as the reference computes it on
 //                           a hit; only the winning triangle's is ever fetched
 //   DLight lights[n_light]  32 B
@@ -31,7 +33,8 @@ struct DTri {
   float nx, ny, nz;     // a x b (prefilter only)
   float ke;             // kappa * emax,   emax = max|component of a,b| (prefilter error scale)
   float ke2;            // kappa * emax^2
-  float pad0, pad1;
+  uint32_t orig;        // index of this triangle in the ORIGINAL (file-order) array: tie-break key
+  float pad1;
 };
 static_assert(sizeof(DTri) == 64, "DTri must be one 64-byte line");
 
@@ -40,11 +43,13 @@ struct DObj {
   uint32_t mat;         // material index
   uint32_t tri_begin;   // mesh: first DTri; triangle: its DTri
   uint32_t tri_count;   // mesh: number of triangles; triangle: 1
+  uint32_t node_begin;  // mesh: first DNode of its BVH
+  uint32_t node_count;  // mesh: number of BVH nodes
   // triangle: unused
   // mesh    : f[0..2] bbox.min, f[3..5] bbox.max
   // plane   : f[0..2] point,    f[3..5] normal
   // sphere  : f[0..2] center,   f[3] radius, f[4] radius*radius
-  float f[12];
+  float f[10];
 };
 static_assert(sizeof(DObj) == 64, "DObj must be 64 bytes");
 
@@ -74,6 +79,7 @@ enum : uint32_t {
   KV_PREFILTER = 1u,   // conservative FMA prefilter before the exact Cramer test
   KV_ANYHIT = 2u,      // shadow casts stop at the first occluder (all-opaque scenes only)
   KV_COUNT = 4u,       // also accumulate algorithmic-byte counters
+  KV_BVH = 8u,         // walk each mesh through its BVH instead of linearly
 };
 
 struct DRows {
@@ -87,6 +93,7 @@ struct DRows {
 struct RenderLaunch {
   const DObj *objs;
   const DTri *tris;
+  const void *nodes;    // DNode[] (bvh.h)
   const float *gnorm;   // 4 floats per triangle
   const DLight *lights;
   const DMat *mats;

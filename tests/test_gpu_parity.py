@@ -43,7 +43,7 @@ def test_gpu_matches_golden(gpu, path):
     assert r["max_depth"] == np.float32(want_max)
 
 
-VARIANTS = [0, 1, 2, 4, 2 | 4]  # AUTO, (LDS reserved), NO_PREFILTER, NO_ANYHIT, both
+VARIANTS = [0, 2, 4, 8, 4 | 8, 2 | 4 | 8]  # AUTO, NO_PREFILTER, NO_ANYHIT, NO_CLUSTER(BVH off), combos
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -59,11 +59,11 @@ def test_gpu_matches_oracle_all_variants(gpu, name, w, h, b, variant):
 
 
 def test_variants_agree_bitwise_at_full_resolution(gpu):
-    """prefilter / any-hit are pure accelerations: at 1920x1080 every buffer must be
+    """prefilter / any-hit / BVH are pure accelerations: at 1920x1080 every buffer must be
     bit-identical with them on and off (size-independent property, no oracle needed)."""
     s = load_scene(gpu, "bunny")
     ds = gpu.DeviceScene(s)
-    ds.set_variant(gpu.VAR_NO_PREFILTER | gpu.VAR_NO_ANYHIT)
+    ds.set_variant(gpu.VAR_NO_PREFILTER | gpu.VAR_NO_ANYHIT | gpu.VAR_NO_CLUSTER)
     a = ds.render()
     ds.set_variant(gpu.VAR_AUTO)
     b = ds.render()
