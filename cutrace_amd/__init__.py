@@ -20,6 +20,8 @@ VAR_TRI_LDS = 1
 VAR_NO_PREFILTER = 2
 VAR_NO_ANYHIT = 4
 VAR_NO_CLUSTER = 8
+VAR_STATS = 16
+VAR_EXACT_POW = 32
 
 
 @contextlib.contextmanager

@@ -117,7 +117,7 @@ def hip_lib():
     """The HIP C-ABI library.  Fails loudly when it is missing: there is no fallback."""
     global _hip
     if _hip is None:
-        path = os.path.join(PKG, "libcutrace_amd.so")
+        path = os.environ.get("CUTRACE_AMD_LIB") or os.path.join(PKG, "libcutrace_amd.so")  # override: tuning builds
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: the HIP extension is not built; refusing to fall back to CPU")
         # the CLI links both libs; load host first so shared symbols resolve identically

@@ -83,6 +83,7 @@ struct ctr_scene {
   uint32_t n_obj = 0, n_tri = 0, n_light = 0, n_mat = 0;
   bool has_mesh = false;
   bool all_opaque = true;
+  bool need_cold = false;
   DCam cam{};
   uint32_t user_variant = CTR_VAR_AUTO;
   // cached device outputs for the host-buffer form
@@ -99,7 +100,9 @@ struct ctr_scene {
     // (SURVEY §8(a) row a9); with any transparency the ordered nearest-hit loop is kept
     if (all_opaque && !(user_variant & CTR_VAR_NO_ANYHIT) && !count) kv |= KV_ANYHIT;
     if (!(user_variant & CTR_VAR_NO_CLUSTER) && !count) kv |= KV_BVH;
+    if (!(user_variant & CTR_VAR_EXACT_POW)) kv |= KV_FASTPOW;
     if (count) kv = KV_PREFILTER | KV_COUNT;  // the counting launch walks like the reference
+    if (user_variant & CTR_VAR_STATS) kv = KV_STATS | (all_opaque ? KV_ANYHIT : 0u);
     return kv;
   }
 };
@@ -153,6 +156,7 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.n_light = s->n_light;
   L.n_mat = s->n_mat;
   L.has_mesh = s->has_mesh ? 1u : 0u;
+  L.need_cold_frames = s->need_cold ? 1u : 0u;
   L.cam = s->cam;
 }
 
@@ -294,11 +298,12 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     lights[i] = DLight{l.type, l.v.x, l.v.y, l.v.z, l.color.x, l.color.y, l.color.z, 0.f};
   }
   std::vector<DMat> mats(d->n_materials);
-  bool all_opaque = true;
+  bool all_opaque = true, need_cold = false;
   for (uint64_t i = 0; i < d->n_materials; i++) {
     const ctr_material &m = d->materials[i];
     mats[i] = DMat{m.color.x, m.color.y, m.color.z, m.specular, m.reflexivity, m.phong_exp, m.transparency, 0.f};
     if (!(m.transparency == 0.0f)) all_opaque = false;
+    if ((double)m.transparency >= 1e-6 && (double)m.reflexivity >= 1e-6) need_cold = true;
   }
 
   auto *s = new ctr_scene();
@@ -309,6 +314,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->n_mat = (uint32_t)mats.size();
   s->has_mesh = has_mesh;
   s->all_opaque = all_opaque;
+  s->need_cold = need_cold;
   const ctr_camera &c = d->cam;
   DCam cam{};
   cam.pos[0] = c.pos.x; cam.pos[1] = c.pos.y; cam.pos[2] = c.pos.z;
@@ -334,7 +340,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
       (er = upload((void **)&s->d_gnorm, gn.data(), gn.size() * sizeof(float))) != hipSuccess ||
       (er = upload((void **)&s->d_lights, lights.data(), lights.size() * sizeof(DLight))) != hipSuccess ||
       (er = upload((void **)&s->d_mats, mats.data(), mats.size() * sizeof(DMat))) != hipSuccess ||
-      (er = hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess ||
+      (er = hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
       (er = hipEventCreate(&s->ev0)) != hipSuccess || (er = hipEventCreate(&s->ev1)) != hipSuccess) {
     ctr_scene_destroy(s);
     return hip_fail(er, "scene upload");
@@ -413,7 +419,7 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   L.normal = s->d_normal;
   L.counters = s->d_counters;
   L.variant = s->kernel_variant(count);
-  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), nullptr));
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), nullptr));
   HIP_TRY(hipEventRecord(s->ev0, nullptr));
   int e = ctr_launch_render(L, nullptr);
   if (e) return hip_fail((hipError_t)e, "render kernel launch");
@@ -427,8 +433,11 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
     if (color3) HIP_TRY(hipMemcpy(color3, s->d_color, sizeof(float) * 3 * px, hipMemcpyDeviceToHost));
     if (normal3) HIP_TRY(hipMemcpy(normal3, s->d_normal, sizeof(float) * 3 * px, hipMemcpyDeviceToHost));
   }
-  unsigned long long cnt[4] = {0, 0, 0, 0};
+  unsigned long long cnt[16] = {0};
   HIP_TRY(hipMemcpy(cnt, s->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  if (s->user_variant & CTR_VAR_STATS)
+    fprintf(stderr, "cutrace_amd stats: wave_casts=%llu nodes=%llu tri_prefilter=%llu tri_exact=%llu mesh_entries=%llu "
+                    "active_lanes=%llu kernel_ms=%.3f\n", cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], cnt[9], ms);
   if (aabb_tris) *aabb_tris = cnt[2];
   auto t1 = std::chrono::high_resolution_clock::now();
   if (stats) {

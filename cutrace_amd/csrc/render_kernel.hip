@@ -46,8 +46,21 @@
 
 namespace {
 
-constexpr int TW = 8, TH = 8;           // pixel tile of one wave
-constexpr int WAVES_PER_WG = 4;
+#ifndef CTR_TW
+#define CTR_TW 8
+#endif
+#ifndef CTR_TH
+#define CTR_TH 8
+#endif
+#ifndef CTR_WAVES_PER_WG
+#define CTR_WAVES_PER_WG 1
+#endif
+#ifndef CTR_MIN_WAVES_EU
+#define CTR_MIN_WAVES_EU 1
+#endif
+constexpr int TW = CTR_TW, TH = CTR_TH;  // pixel tile of one wave (TW*TH == 64)
+static_assert(TW * TH == 64, "one wave = one TW x TH tile");
+constexpr int WAVES_PER_WG = CTR_WAVES_PER_WG;
 constexpr int WG_THREADS = 64 * WAVES_PER_WG;
 constexpr int MAX_DEPTH = CTR_MAX_BOUNCES + 1;
 
@@ -74,13 +87,15 @@ __device__ __forceinline__ float det3(V3 c0, V3 c1, V3 c2) {
 __device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }
 
-struct Frame {            // one suspended ray_color activation (shading.hpp:116-154)
-  float r, g, b;          // rgb so far
-  float refl, transl;
-  float px, py, pz;       // incoming->start + distance * incoming->dir
-  float dx, dy, dz;       // incoming->dir
-  int bl_stage;           // bounces_left << 2 | stage (1 = waiting for reflection, 2 = for pass-through)
-};
+// A suspended ray_color activation (shading.hpp:116-154) lives in LDS, never in scratch:
+//   hot  fields 0..5 : rgb so far (3), reflective, translucent, stage (1 = waiting for the
+//                      reflection child, 2 = for the pass-through child)
+//   cold fields 6..11: incoming->start + distance*incoming->dir (3), incoming->dir (3); only
+//                      materials that BOTH reflect and transmit need them (A.nf == 12)
+// Layout [wave][frame][field][lane]: lane-contiguous dwords, so a push/pop is conflict-free
+// whatever each lane's own stack depth is.  bounces_left of a frame is implied by its depth
+// (every push decrements it): bl = bounces - depth.
+enum { F_R = 0, F_G, F_B, F_REFL, F_TRANSL, F_STAGE, F_PX, F_PY, F_PZ, F_DX, F_DY, F_DZ };
 
 struct KArgs {
   const CADDR DObj *objs;
@@ -95,13 +110,15 @@ struct KArgs {
   float fudge;
   int bounces;
   uint32_t has_mesh;
+  uint32_t nf;        // LDS dwords per stack frame: 6, or 12 when some material reflects AND transmits
+  uint32_t frames;    // LDS stack frames per lane (= max(bounces, 1))
 };
 
 enum { M_RADIANCE = 0, M_SHADOW = 1, M_DONE = 2 };
 enum { ACT_NONE = 0, ACT_LIGHT = 1, ACT_BOUNCE = 2, ACT_UNWIND = 3 };
 
 template <uint32_t KV>
-__global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__restrict__ depth_out,
+__global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KArgs A, float *__restrict__ depth_out,
                                                             float *__restrict__ color_out,
                                                             float *__restrict__ normal_out,
                                                             unsigned long long *__restrict__ counters) {
@@ -109,6 +126,11 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
   constexpr bool ANYHIT = (KV & KV_ANYHIT) != 0;
   constexpr bool COUNT = (KV & KV_COUNT) != 0;
   constexpr bool BVH = (KV & KV_BVH) != 0;
+  constexpr bool STATS = (KV & KV_STATS) != 0;
+  constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
+  // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
+  // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast
+  unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
 
   const uint32_t w = A.cam.w, h = A.cam.h;
   const uint32_t lane = threadIdx.x & 63u;
@@ -148,11 +170,13 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
   int mode = in_image ? M_RADIANCE : M_DONE;
   bool first = true;
   float min_t = A.fudge;
-  int bl = A.bounces;       // bounces left for the current ray_color activation
-  int sp = 0;               // stack pointer
-  Frame stack[MAX_DEPTH];
-  V3 in_o = ro, in_d = rd;  // the radiance ray being shaded ("incoming")
+  int sp = 0;               // stack depth; bounces left for the current activation = bounces - sp
+  extern __shared__ float lds_stack[];
+  float *const stk = lds_stack + (size_t)(threadIdx.x >> 6) * A.frames * A.nf * 64 + lane;
+#define STK(frame, field) stk[((frame) * A.nf + (field)) * 64]
+  V3 in_d = rd;             // direction of the radiance ray being shaded ("incoming"); its start is `ro` until the hit
   V3 hit = mk(0, 0, 0), nn = mk(0, 0, 0), pos = mk(0, 0, 0);
+  V3 in_dn = mk(0, 0, 0);   // incoming->dir.normalized() (shading.hpp:90,131; default_schema.hpp:245)
   V3 fin = mk(0, 0, 0);     // phong accumulator ("final")
   V3 nd = mk(0, 0, 0);      // normalized direction to the current light
   float light_dist = 0.f, intensity = 0.f;
@@ -166,6 +190,7 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
     const bool active = mode != M_DONE;
     const bool shadow_cast = mode == M_SHADOW;
     n_casts += active ? 1u : 0u;
+    if (STATS) { st[0]++; st[5] += __builtin_popcountll(BALLOT(active)); }
 
     // =====================================================================
     // ray_cast (ray_cast.hpp:29-55): nearest hit of (ro, rd) over all objects
@@ -204,6 +229,7 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
         if (BALLOT(bb) == 0ull) continue;  // no lane of this wave needs the mesh
         const uint32_t beg = O.tri_begin, cnt = O.tri_count;
         if (COUNT) n_aabb_tris += bb ? (unsigned long long)cnt : 0ull;
+        if (STATS) st[4]++;
         // ---- mesh::intersect, default_schema.hpp:125-144: smallest valid t, FIRST triangle in
         //      file order on ties (strict < over file order)  ==  lexicographic min of (t, orig) ----
         float mt = INFINITY;
@@ -213,6 +239,7 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
         // one triangle against the lanes in `lanes` (wave-uniform T: SGPR operands)
         auto tri_test = [&](const CADDR DTri &T, uint32_t tri_index, bool lanes) {
           bool c = lanes;
+          if (STATS) st[2]++;
           if (PREFILTER) {
             // Conservative reject test.  Same quantities as the exact test
             // (alpha = det[a b c], A1 = det[d b c], A2 = det[a d c]) evaluated with FMAs
@@ -236,6 +263,7 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
             c = lanes && (!rej || (absa <= E));
           }
           if (BALLOT(c) != 0ull) {
+            if (STATS) st[3]++;
             if (c) {
               // ---- triangle::intersect, default_schema.hpp:57-78, reference op order ----
               const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
@@ -269,14 +297,16 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
           const float gz = fmaxf(fabsf(O.f[2] - ro.z), fabsf(O.f[5] - ro.z));
           const float slack = (fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f) *
                               fmaxf(fmaxf(fabsf(rinv.x), fabsf(rinv.y)), fabsf(rinv.z));
+          const V3 roi = mk(ro.x * rinv.x, ro.y * rinv.y, ro.z * rinv.z);  // box test as fma(b, 1/d, -o/d)
           const CADDR DNode *nodes = A.nodes + O.node_begin;
           const uint32_t n_nodes = O.node_count;
           uint32_t ni = 0;
           while (ni < n_nodes) {
             const CADDR DNode &N = nodes[ni];
-            const float t1x = (N.mnx - ro.x) * rinv.x, t2x = (N.mxx - ro.x) * rinv.x;
-            const float t1y = (N.mny - ro.y) * rinv.y, t2y = (N.mxy - ro.y) * rinv.y;
-            const float t1z = (N.mnz - ro.z) * rinv.z, t2z = (N.mxz - ro.z) * rinv.z;
+            if (STATS) st[1]++;
+            const float t1x = __builtin_fmaf(N.mnx, rinv.x, -roi.x), t2x = __builtin_fmaf(N.mxx, rinv.x, -roi.x);
+            const float t1y = __builtin_fmaf(N.mny, rinv.y, -roi.y), t2y = __builtin_fmaf(N.mxy, rinv.y, -roi.y);
+            const float t1z = __builtin_fmaf(N.mnz, rinv.z, -roi.z), t2z = __builtin_fmaf(N.mxz, rinv.z, -roi.z);
             const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
             const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
             // reject only on a definite miss (NaN compares false -> the node is entered)
@@ -308,9 +338,18 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
       } else if (type == CTR_OBJ_PLANE) {
         // ---- plane::intersect, default_schema.hpp:189-201 ----
         const V3 p = mk(O.f[0], O.f[1], O.f[2]), n = mk(O.f[3], O.f[4], O.f[5]);
-        const float t0 = vdot(vsub(p, ro), n) / vdot(rd, n);
-        ok = __builtin_isfinite(t0) && min_t <= t0;
-        cand = t0;
+        const float num = vdot(vsub(p, ro), n), den = vdot(rd, n);
+        // The IEEE division is only worth doing where the quotient can matter: skip it (for the
+        // whole wave) when a 1-ulp reciprocal already proves t0 < min_t or t0 >= the current bound.
+        const float ta = num * __builtin_amdgcn_rcpf(den);
+        const float mrg = fabsf(ta) * 0x1p-18f + 1e-30f;
+        const float lim_hi = (ANYHIT && shadow_cast) ? light_dist : best;
+        const bool need = live && !(((ta + mrg) < min_t) | ((ta - mrg) >= lim_hi));  // NaN/inf -> needed
+        if (BALLOT(need) != 0ull) {
+          const float t0 = num / den;
+          ok = need && __builtin_isfinite(t0) && min_t <= t0;
+          cand = t0;
+        }
       } else if (type == CTR_OBJ_SPHERE) {
         // ---- sphere::intersect, default_schema.hpp:226-251 ----
         const V3 d = vnormalized(rd), c = mk(O.f[0], O.f[1], O.f[2]);
@@ -360,11 +399,12 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
       if (was_hit) {
         const CADDR DObj &H = A.objs[bobj];
         mat_i = H.mat;
-        pos = vadd(in_o, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
+        pos = vadd(ro, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
+        in_dn = vnormalized(in_d);
         const uint32_t ht = H.type;
         if (ht == CTR_OBJ_SPHERE) {
           // default_schema.hpp:245-246: hit uses the NORMALIZED direction
-          hit = vadd(in_o, vscale(vnormalized(in_d), best));
+          hit = vadd(ro, vscale(in_dn, best));
           normal = vnormalized(vsub(hit, mk(H.f[0], H.f[1], H.f[2])));
         } else if (ht == CTR_OBJ_PLANE) {
           hit = pos;
@@ -420,8 +460,16 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
           const V3 color = mk(Lg.cx, Lg.cy, Lg.cz);
           const float fd = smax(0.0f, vdot(nn, nd));
           const V3 ld = vmul(diffuse, color);
-          const V3 hv = vnormalized(vadd(vscale(vnormalized(in_d), -1.0f), nd));
-          const float fs = (float)pow((double)smax(0.0f, vdot(nn, hv)), (double)M.phong_exp);
+          const V3 hv = vnormalized(vadd(vscale(in_dn, -1.0f), nd));
+          const float sx = smax(0.0f, vdot(nn, hv));
+          float fs;
+          if (FASTPOW) {
+            // exp2(e*log2(x)) on the f32 transcendental pipe: relative error ~1e-6 wherever the
+            // result is not negligible; feeds only the specular colour term (<= 1e-6 absolute)
+            fs = (M.phong_exp == 0.0f) ? 1.0f : __builtin_amdgcn_exp2f(M.phong_exp * __builtin_amdgcn_logf(sx));
+          } else {
+            fs = (float)pow((double)sx, (double)M.phong_exp);  // f64, rounded once: <= 1 ulp from glibc powf
+          }
           const V3 ls = vmul(specular, color);
           fin = vadd(fin, vscale(vadd(vscale(ld, fd), vscale(ls, fs)), 1 - shadow_fac));
         }
@@ -460,24 +508,23 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
       // shading.hpp:126-150 with rgb = fin
       const CADDR DMat &M = A.mats[mat_i];
       const float reflective = M.reflexivity, translucent = M.transparency;
-      const bool do_refl = bl != 0 && (double)reflective >= 1e-6;
-      const bool do_trans = bl != 0 && (double)translucent >= 1e-6;
+      const bool more = sp < A.bounces;  // `if constexpr (bounces != 0)`
+      const bool do_refl = more && (double)reflective >= 1e-6;
+      const bool do_trans = more && (double)translucent >= 1e-6;
       if (do_refl || do_trans) {
-        Frame f;
-        f.r = fin.x; f.g = fin.y; f.b = fin.z;
-        f.refl = reflective; f.transl = translucent;
-        f.px = pos.x; f.py = pos.y; f.pz = pos.z;
-        f.dx = in_d.x; f.dy = in_d.y; f.dz = in_d.z;
-        f.bl_stage = (bl << 2) | (do_refl ? 1 : 2);
-        stack[sp++] = f;
-        in_o = pos;
+        STK(sp, F_R) = fin.x; STK(sp, F_G) = fin.y; STK(sp, F_B) = fin.z;
+        STK(sp, F_REFL) = reflective; STK(sp, F_TRANSL) = translucent;
+        STK(sp, F_STAGE) = do_refl ? 1.0f : 2.0f;
+        if (do_refl && do_trans) {  // the pass-through child is cast after the reflection returns
+          STK(sp, F_PX) = pos.x; STK(sp, F_PY) = pos.y; STK(sp, F_PZ) = pos.z;
+          STK(sp, F_DX) = in_d.x; STK(sp, F_DY) = in_d.y; STK(sp, F_DZ) = in_d.z;
+        }
+        sp++;
         if (do_refl) {
           // reflect(nd, nn) = nd - (2*(nn.nd))*nn, vector.hpp:204-206
-          const V3 ndir = vnormalized(in_d);
-          in_d = vsub(ndir, vscale(nn, 2.0f * vdot(nn, ndir)));
+          in_d = vsub(in_dn, vscale(nn, 2.0f * vdot(nn, in_dn)));
         }
-        bl -= 1;
-        ro = in_o; rd = in_d;
+        ro = pos; rd = in_d;
         min_t = A.fudge;
         mode = M_RADIANCE;
       } else {
@@ -496,19 +543,18 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
           mode = M_DONE;
           break;
         }
-        Frame f = stack[--sp];
-        const int stage = f.bl_stage & 3, fbl = f.bl_stage >> 2;
-        V3 rgb = mk(f.r, f.g, f.b);
-        if (stage == 1) {
-          rgb = vadd(rgb, vscale(out_rgb, f.refl));  // shading.hpp:138
-          if ((double)f.transl >= 1e-6) {
-            f.r = rgb.x; f.g = rgb.y; f.b = rgb.z;
-            f.bl_stage = (fbl << 2) | 2;
-            stack[sp++] = f;
-            in_o = mk(f.px, f.py, f.pz);
-            in_d = mk(f.dx, f.dy, f.dz);
-            bl = fbl - 1;
-            ro = in_o; rd = in_d;
+        --sp;
+        V3 rgb = mk(STK(sp, F_R), STK(sp, F_G), STK(sp, F_B));
+        const float f_transl = STK(sp, F_TRANSL);
+        if (STK(sp, F_STAGE) == 1.0f) {
+          rgb = vadd(rgb, vscale(out_rgb, STK(sp, F_REFL)));  // shading.hpp:138
+          if ((double)f_transl >= 1e-6) {
+            STK(sp, F_R) = rgb.x; STK(sp, F_G) = rgb.y; STK(sp, F_B) = rgb.z;
+            STK(sp, F_STAGE) = 2.0f;
+            in_d = mk(STK(sp, F_DX), STK(sp, F_DY), STK(sp, F_DZ));
+            ro = mk(STK(sp, F_PX), STK(sp, F_PY), STK(sp, F_PZ));
+            rd = in_d;
+            sp++;
             min_t = A.fudge;
             mode = M_RADIANCE;
             break;
@@ -516,11 +562,12 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
           out_rgb = rgb;
         } else {
           // shading.hpp:148
-          out_rgb = vadd(vscale(rgb, 1.0f - f.transl), vscale(out_rgb, f.transl));
+          out_rgb = vadd(vscale(rgb, 1.0f - f_transl), vscale(out_rgb, f_transl));
         }
       }
     }
   }
+#undef STK
 
   // ---- per-wave reductions -> 2-3 atomics per wave ----
   if (counters) {
@@ -532,6 +579,9 @@ __global__ __launch_bounds__(WG_THREADS) void render_kernel(KArgs A, float *__re
       uint32_t o = (uint32_t)__shfl_xor((int)dbits, off);
       dbits = o > dbits ? o : dbits;
       if (COUNT) t += __shfl_xor(t, off);
+    }
+    if (STATS && lane == 0) {
+      for (int q = 0; q < 6; q++) atomicAdd(&counters[4 + q], st[q]);
     }
     if (lane == 0) {
       atomicAdd(&counters[0], c);
@@ -557,13 +607,30 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.fudge = L.fudge;
   A.bounces = L.bounces;
   A.has_mesh = L.has_mesh;
+  A.nf = L.need_cold_frames ? 12u : 6u;
+  A.frames = (uint32_t)(L.bounces > 0 ? L.bounces : 1);
+  const size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
   const uint32_t tiles_x = (L.cam.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
   const uint64_t waves = (uint64_t)tiles_x * tiles_y;
   if (waves == 0) return 0;
   const uint32_t grid = (uint32_t)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
-  hipLaunchKernelGGL(render_kernel<KV>, dim3(grid), dim3(WG_THREADS), 0, stream, A, L.depth, L.color, L.normal,
+  hipLaunchKernelGGL(render_kernel<KV>, dim3(grid), dim3(WG_THREADS), lds_bytes, stream, A, L.depth, L.color, L.normal,
                      L.counters);
   return (int)hipGetLastError();
+}
+
+template <uint32_t BASE>
+int launch_main(const RenderLaunch &L, hipStream_t s) {
+  switch (L.variant & (KV_PREFILTER | KV_ANYHIT | KV_BVH)) {
+    case 0: return launch<BASE>(L, s);
+    case KV_PREFILTER: return launch<BASE | KV_PREFILTER>(L, s);
+    case KV_ANYHIT: return launch<BASE | KV_ANYHIT>(L, s);
+    case KV_PREFILTER | KV_ANYHIT: return launch<BASE | KV_PREFILTER | KV_ANYHIT>(L, s);
+    case KV_BVH: return launch<BASE | KV_BVH>(L, s);
+    case KV_BVH | KV_PREFILTER: return launch<BASE | KV_BVH | KV_PREFILTER>(L, s);
+    case KV_BVH | KV_ANYHIT: return launch<BASE | KV_BVH | KV_ANYHIT>(L, s);
+    default: return launch<BASE | KV_BVH | KV_PREFILTER | KV_ANYHIT>(L, s);
+  }
 }
 
 }  // namespace
@@ -571,14 +638,8 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
 int ctr_launch_render(const RenderLaunch &L, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (L.variant & KV_COUNT) return launch<KV_PREFILTER | KV_COUNT>(L, s);
-  switch (L.variant & (KV_PREFILTER | KV_ANYHIT | KV_BVH)) {
-    case 0: return launch<0>(L, s);
-    case KV_PREFILTER: return launch<KV_PREFILTER>(L, s);
-    case KV_ANYHIT: return launch<KV_ANYHIT>(L, s);
-    case KV_PREFILTER | KV_ANYHIT: return launch<KV_PREFILTER | KV_ANYHIT>(L, s);
-    case KV_BVH: return launch<KV_BVH>(L, s);
-    case KV_BVH | KV_PREFILTER: return launch<KV_BVH | KV_PREFILTER>(L, s);
-    case KV_BVH | KV_ANYHIT: return launch<KV_BVH | KV_ANYHIT>(L, s);
-    default: return launch<KV_BVH | KV_PREFILTER | KV_ANYHIT>(L, s);
-  }
+  if (L.variant & KV_STATS)
+    return (L.variant & KV_ANYHIT) ? launch<KV_BVH | KV_PREFILTER | KV_ANYHIT | KV_FASTPOW | KV_STATS>(L, s)
+                                   : launch<KV_BVH | KV_PREFILTER | KV_FASTPOW | KV_STATS>(L, s);
+  return (L.variant & KV_FASTPOW) ? launch_main<KV_FASTPOW>(L, s) : launch_main<0>(L, s);
 }

@@ -80,6 +80,8 @@ enum : uint32_t {
   KV_ANYHIT = 2u,      // shadow casts stop at the first occluder (all-opaque scenes only)
   KV_COUNT = 4u,       // also accumulate algorithmic-byte counters
   KV_BVH = 8u,         // walk each mesh through its BVH instead of linearly
+  KV_STATS = 16u,      // diagnostic: wave-level work counters into counters[4..9]
+  KV_FASTPOW = 32u,    // specular pow() as exp2(e*log2(x)) in f32 instead of f64 pow
 };
 
 struct DRows {
@@ -99,6 +101,7 @@ struct RenderLaunch {
   const DMat *mats;
   uint32_t n_obj, n_light, n_mat;
   uint32_t has_mesh;
+  uint32_t need_cold_frames;  // some material both reflects and transmits (>= 1e-6 each)
   DCam cam;
   DRows rows;
   float fudge;
@@ -106,7 +109,7 @@ struct RenderLaunch {
   float *depth;
   float *color;
   float *normal;
-  unsigned long long *counters;  // [0] ray_count, [1] max-depth bits, [2] AABB-hit triangle count (KV_COUNT)
+  unsigned long long *counters;  // [0] ray_count, [1] max-depth bits, [2] AABB-hit triangle count (KV_COUNT), [4..9] KV_STATS
   uint32_t variant;
 };
 

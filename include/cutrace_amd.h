@@ -178,7 +178,9 @@ int ctr_render_device(ctr_scene *scene, float fudge, int bounces, const ctr_rows
 #define CTR_VAR_TRI_LDS 1u        /* mesh triangles staged in LDS (else wave-uniform scalar loads) */
 #define CTR_VAR_NO_PREFILTER 2u   /* run the exact Cramer test on every triangle */
 #define CTR_VAR_NO_ANYHIT 4u      /* never use the any-hit shadow early-out */
-#define CTR_VAR_NO_CLUSTER 8u     /* ignore triangle-cluster culling */
+#define CTR_VAR_NO_CLUSTER 8u     /* walk meshes linearly instead of through their BVH */
+#define CTR_VAR_EXACT_POW 32u     /* specular pow() in f64 (<=1 ulp of glibc powf) instead of f32 exp2/log2 */
+#define CTR_VAR_STATS 16u         /* diagnostic build: print wave-level work counters to stderr */
 int ctr_set_variant(ctr_scene *scene, uint32_t variant_bits);
 
 /* Algorithmic bytes: 56·n_objects per ray_cast + 48·n_tri for

@@ -43,7 +43,7 @@ def test_gpu_matches_golden(gpu, path):
     assert r["max_depth"] == np.float32(want_max)
 
 
-VARIANTS = [0, 2, 4, 8, 4 | 8, 2 | 4 | 8]  # AUTO, NO_PREFILTER, NO_ANYHIT, NO_CLUSTER(BVH off), combos
+VARIANTS = [0, 32, 2, 4, 8, 4 | 8, 2 | 4 | 8 | 32]  # AUTO, EXACT_POW, NO_PREFILTER, NO_ANYHIT, NO_CLUSTER(BVH off), combos
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -63,9 +63,9 @@ def test_variants_agree_bitwise_at_full_resolution(gpu):
     bit-identical with them on and off (size-independent property, no oracle needed)."""
     s = load_scene(gpu, "bunny")
     ds = gpu.DeviceScene(s)
-    ds.set_variant(gpu.VAR_NO_PREFILTER | gpu.VAR_NO_ANYHIT | gpu.VAR_NO_CLUSTER)
+    ds.set_variant(gpu.VAR_NO_PREFILTER | gpu.VAR_NO_ANYHIT | gpu.VAR_NO_CLUSTER | gpu.VAR_EXACT_POW)
     a = ds.render()
-    ds.set_variant(gpu.VAR_AUTO)
+    ds.set_variant(gpu.VAR_EXACT_POW)
     b = ds.render()
     for k in ("depth", "normal", "color"):
         assert same_bits(a[k], b[k]), k
