@@ -109,9 +109,14 @@ def main():
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
 
+    step_no = [0]
+
     def render_step(events=None):
+        slot = step_no[0] % tiler.slots
+        step_no[0] += 1
+        tiler.begin(slot)  # the gather that last used this half of the double buffer must be done
         for f in range(frames):
-            d, c, n = tiler.views(f)
+            d, c, n = tiler.views(slot, f)
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
@@ -120,9 +125,10 @@ def main():
             if events is not None:
                 e1.record(stream)
                 events.append((e0, e1))
-        tiler.gather()
+        tiler.gather(slot)  # asynchronous: overlaps with the next step's rendering
 
     def barrier():
+        tiler.finish()      # every outstanding gather / re-interleave completes INSIDE the timed region
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -130,7 +136,7 @@ def main():
     # rays per step for this rank (counting launch, untimed)
     counters.zero_()
     render_step()
-    torch.cuda.synchronize()
+    barrier()
     rays_rank_step = int(counters[0].item())
     for _ in range(max(0, args.warmup - 1)):
         render_step()
@@ -160,8 +166,13 @@ def main():
         alg_bytes, alg_rays = ds.algorithmic_bytes(bounces=args.bounces, rows=tiler.rows)
         achieved = alg_bytes / (kern_avg * 1e-3) / 1e9 if kern_avg > 0 else 0.0
         traffic = None
-        if args.traffic_json and os.path.exists(args.traffic_json):
-            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+        tj = args.traffic_json or os.path.join(ROOT, "profiles", "traffic.json")
+        if world == 1 and os.path.exists(tj):
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # separate runs, gfx950 correction applied by scripts/pmc_traffic.py); same workload only
+            t_ = json.load(open(tj))
+            if t_.get("workload") == f"{os.path.basename(args.scene)}@{w}x{h}b{args.bounces}":
+                traffic = t_.get("hbm_bytes_per_launch")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "render_kernel",
                 "kernel_ms_avg": kern_avg, "algorithmic_bytes_per_launch": alg_bytes,

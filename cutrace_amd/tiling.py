@@ -7,9 +7,15 @@ three buffers to rank 0, which re-interleaves them into the grid<> layout.
 Rows are dealt in interleaved blocks (block b -> rank b % world) because contiguous bands are
 badly balanced (rows crossing the mesh cost far more than wall-only rows).
 
-The module is renderer-agnostic: `render_rows(frame_index, rows_tuple, out_views)` fills this
-rank's compact buffers.  bench.py passes the HIP path (ctr_render_device); the gloo CPU tests
-pass the oracle, which is the only place the oracle may be used.
+Pipelining: the gather of step k runs on the communication stream (RCCL's own) and the
+re-interleave on a side stream while step k+1 is being rendered into the other half of a
+double buffer — xGMI is point-to-point (7 links per GPU), so the 7 incoming messages of rank 0
+ride 7 different links, but they are still ~1 ms for 58 MB each and must not serialise with
+rendering.  `finish()` drains everything (called inside the timed region by bench.py).
+
+The module is renderer-agnostic: the caller fills `views(slot, frame)` with this rank's compact
+buffers.  bench.py uses the HIP path (ctr_render_device); the gloo CPU tests use the oracle,
+which is the only place the oracle may be used.
 """
 import torch
 import torch.distributed as dist
@@ -29,62 +35,106 @@ def max_part_rows(h, n_parts, block_rows=BLOCK_ROWS):
 class FrameTiler:
     """Buffers and index tables for rendering `frames` frames of w x h per step on `world` ranks."""
 
-    def __init__(self, w, h, frames, rank, world, device, block_rows=BLOCK_ROWS):
+    def __init__(self, w, h, frames, rank, world, device, block_rows=BLOCK_ROWS, slots=2):
         self.w, self.h, self.frames, self.rank, self.world = w, h, frames, rank, world
-        self.device = device
+        self.device = torch.device(device)
         self.block_rows = block_rows
         self.rows = (0, h, block_rows, rank, world) if world > 1 else None
         self.my_rows = part_rows(h, rank, world, block_rows) if world > 1 else list(range(h))
         self.cap = max_part_rows(h, world, block_rows) if world > 1 else h  # padded rows per rank
+        self.slots = slots if world > 1 else 1
         f32 = torch.float32
         per = frames * self.cap * w
-        # packed local buffer: [depth | color | normal], 7 floats per pixel
-        self.local = torch.zeros(7 * per, dtype=f32, device=device)
+        self.per = per
+        # packed local buffers (one per pipeline slot): [depth | color | normal], 7 floats per pixel
+        self.local = [torch.zeros(7 * per, dtype=f32, device=self.device) for _ in range(self.slots)]
         self.sec = (0, per, 4 * per, 7 * per)
         self.gathered = None
         self.final = None
+        self.pending = [None] * self.slots      # outstanding gather per slot
+        self.side = None                         # side stream for the re-interleave on rank 0
+        self.assembled = [None] * self.slots     # event: slot's frames are in `final`
+        self.is_cuda = self.device.type == "cuda"
         if rank == 0:
             if world > 1:
-                self.gathered = torch.zeros(world, 7 * per, dtype=f32, device=device)
+                self.gathered = [torch.zeros(world, 7 * per, dtype=f32, device=self.device) for _ in range(self.slots)]
                 # position of global row y inside the (world*cap) padded row axis
                 perm = torch.empty(h, dtype=torch.int64)
                 for p in range(world):
                     for k, y in enumerate(part_rows(h, p, world, block_rows)):
                         perm[y] = p * self.cap + k
-                self.perm = perm.to(device)
-            self.final = dict(depth=torch.zeros(frames, h, w, dtype=f32, device=device),
-                              color=torch.zeros(frames, h, w, 3, dtype=f32, device=device),
-                              normal=torch.zeros(frames, h, w, 3, dtype=f32, device=device))
+                self.perm = perm.to(self.device)
+                if self.is_cuda:
+                    self.side = torch.cuda.Stream(device=self.device)
+            self.final = dict(depth=torch.zeros(frames, h, w, dtype=f32, device=self.device),
+                              color=torch.zeros(frames, h, w, 3, dtype=f32, device=self.device),
+                              normal=torch.zeros(frames, h, w, 3, dtype=f32, device=self.device))
 
-    def views(self, frame):
-        """Compact (rows_local x w) views of this rank's buffers for one frame."""
+    def views(self, slot, frame):
+        """Compact (rows_local x w) views of this rank's buffers for one frame of one slot."""
         n, w, cap = len(self.my_rows), self.w, self.cap
         d0, c0, n0, _ = self.sec
-        d = self.local[d0 + frame * cap * w: d0 + frame * cap * w + n * w]
-        c = self.local[c0 + 3 * frame * cap * w: c0 + 3 * frame * cap * w + 3 * n * w]
-        m = self.local[n0 + 3 * frame * cap * w: n0 + 3 * frame * cap * w + 3 * n * w]
+        buf = self.local[slot]
+        d = buf[d0 + frame * cap * w: d0 + frame * cap * w + n * w]
+        c = buf[c0 + 3 * frame * cap * w: c0 + 3 * frame * cap * w + 3 * n * w]
+        m = buf[n0 + 3 * frame * cap * w: n0 + 3 * frame * cap * w + 3 * n * w]
         return d, c, m
 
-    def gather(self):
-        """The one collective of the path: packed local buffers -> rank 0, then re-interleave
-        into the final row-major frames (device side)."""
+    def begin(self, slot):
+        """Call before rendering into `slot`: its previous gather (two steps ago) must be done."""
+        if self.world == 1:
+            return
+        self._wait(slot)
+
+    def _wait(self, slot):
+        work = self.pending[slot]
+        if work is not None:
+            work.wait()           # current stream waits for the collective
+            self.pending[slot] = None
+        ev = self.assembled[slot]
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self.assembled[slot] = None
+
+    def gather(self, slot):
+        """The one collective of the path, asynchronous: packed local buffers of `slot` -> rank 0;
+        rank 0 then re-interleaves them into the final row-major frames on a side stream."""
         if self.world == 1:
             F, h, w = self.frames, self.h, self.w
             d0, c0, n0, e = self.sec
-            self.final["depth"] = self.local[d0:c0].view(F, h, w)
-            self.final["color"] = self.local[c0:n0].view(F, h, w, 3)
-            self.final["normal"] = self.local[n0:e].view(F, h, w, 3)
+            buf = self.local[0]
+            self.final["depth"] = buf[d0:c0].view(F, h, w)
+            self.final["color"] = buf[c0:n0].view(F, h, w, 3)
+            self.final["normal"] = buf[n0:e].view(F, h, w, 3)
             return
         if self.rank == 0:
-            dist.gather(self.local, [self.gathered[i] for i in range(self.world)], dst=0)
-            self.assemble()
+            work = dist.gather(self.local[slot], [self.gathered[slot][i] for i in range(self.world)], dst=0,
+                               async_op=True)
+            if self.is_cuda:
+                with torch.cuda.stream(self.side):
+                    work.wait()   # side stream waits for the collective, the render stream does not
+                    self.assemble(slot)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                self.assembled[slot] = ev
+                self.pending[slot] = None
+            else:
+                work.wait()
+                self.assemble(slot)
         else:
-            dist.gather(self.local, None, dst=0)
+            self.pending[slot] = dist.gather(self.local[slot], None, dst=0, async_op=True)
 
-    def assemble(self):
+    def finish(self):
+        """Drain every outstanding gather / re-interleave."""
+        for slot in range(self.slots):
+            self._wait(slot)
+        if self.is_cuda:
+            torch.cuda.synchronize(self.device)
+
+    def assemble(self, slot):
         W, F, cap, w = self.world, self.frames, self.cap, self.w
         d0, c0, n0, e = self.sec
-        g = self.gathered
+        g = self.gathered[slot]
         dep = g[:, d0:c0].view(W, F, cap, w).permute(1, 0, 2, 3).reshape(F, W * cap, w)
         col = g[:, c0:n0].view(W, F, cap, w, 3).permute(1, 0, 2, 3, 4).reshape(F, W * cap, w, 3)
         nor = g[:, n0:e].view(W, F, cap, w, 3).permute(1, 0, 2, 3, 4).reshape(F, W * cap, w, 3)

@@ -1,0 +1,83 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo runs of the row tiling + gather + re-interleave
+(cutrace_amd/tiling.py), with the oracle standing in for the renderer (tests are the only place
+the oracle may be used).  The gathered frames on rank 0 must equal the single-process frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, frames, steps, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cutrace_amd as ca
+    from cutrace_amd.tiling import FrameTiler
+    s = ca.HostScene.load("scene/sphere_plane.json")
+    s.set_size(w, h)
+    tiler = FrameTiler(w, h, frames, rank, world, "cpu")
+    total_rays = 0
+    for step in range(steps):
+        slot = step % tiler.slots
+        tiler.begin(slot)
+        for f in range(frames):
+            r = ca.oracle_render(s, bounces=2 + f, rows=tiler.rows, threads=2)  # frames differ by bounces
+            d, c, n = tiler.views(slot, f)
+            d.copy_(torch.from_numpy(r["depth"]).reshape(-1))
+            c.copy_(torch.from_numpy(r["color"]).reshape(-1))
+            n.copy_(torch.from_numpy(r["normal"]).reshape(-1))
+            total_rays += r["ray_count"]
+        tiler.gather(slot)
+    tiler.finish()
+    t = torch.tensor([total_rays], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        np.savez(out_path, depth=tiler.final["depth"].numpy(), color=tiler.final["color"].numpy(),
+                 normal=tiler.final["normal"].numpy(), rays=int(t[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 40), (3, 37)])
+def test_gather_reassembles_frames(ca, tmp_path, world, h):
+    w, frames, steps = 48, 2, 3
+    out = str(tmp_path / "final.npz")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, frames, steps, out), nprocs=world, join=True)
+    got = np.load(out)
+    s = ca.HostScene.load("scene/sphere_plane.json")
+    s.set_size(w, h)
+    rays = 0
+    for f in range(frames):
+        full = ca.oracle_render(s, bounces=2 + f, threads=4)
+        rays += full["ray_count"]
+        assert np.array_equal(got["depth"][f].view(np.uint32), full["depth"].view(np.uint32))
+        assert np.array_equal(got["color"][f].view(np.uint32), full["color"].view(np.uint32))
+        assert np.array_equal(got["normal"][f].view(np.uint32), full["normal"].view(np.uint32))
+    assert int(got["rays"]) == rays * steps
+
+
+def test_partition_covers_every_row_once():
+    from cutrace_amd.tiling import part_rows, max_part_rows
+    for h in (1, 7, 8, 9, 135, 1080, 4096):
+        for n in (1, 2, 4, 8):
+            rows = sorted(y for p in range(n) for y in part_rows(h, p, n))
+            assert rows == list(range(h))
+            assert max_part_rows(h, n) >= (h + n - 1) // n
+    # 1080 rows over 8 ranks in 8-row blocks: 135 blocks -> 17 or 16 blocks per rank
+    assert [len(part_rows(1080, p, 8)) for p in range(8)] == [136] * 7 + [128]
