@@ -106,6 +106,15 @@ def main():
         ds.set_variant(args.variant)
     frames = world if args.scaling == "weak" else 1
     tiler = FrameTiler(w, h, frames, rank, world, dev)
+    if frames > 1:
+        import ctypes
+        cam0 = hs.desc.contents.cam
+        cams = []
+        for _ in range(frames):  # synthetic camera path: the scene camera repeated
+            c = ca.Camera()
+            ctypes.memmove(ctypes.byref(c), ctypes.byref(cam0), ctypes.sizeof(ca.Camera))
+            cams.append(c)
+        ds.set_cameras(cams)
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
 
@@ -115,16 +124,19 @@ def main():
         slot = step_no[0] % tiler.slots
         step_no[0] += 1
         tiler.begin(slot)  # the gather that last used this half of the double buffer must be done
-        for f in range(frames):
-            d, c, n = tiler.views(slot, f)
-            if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-            ds.render_device(d.data_ptr(), c.data_ptr(), n.data_ptr(), counters.data_ptr(), stream.cuda_stream,
-                             fudge=1e-3, bounces=args.bounces, rows=tiler.rows)
-            if events is not None:
-                e1.record(stream)
-                events.append((e0, e1))
+        buf = tiler.local[slot]
+        d0, c0, n0, _ = tiler.sec
+        esz = buf.element_size()
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        # ONE launch renders this rank's rows of all `frames` frames of the step (camera path batch)
+        ds.render_device_batch(buf.data_ptr() + d0 * esz, buf.data_ptr() + c0 * esz, buf.data_ptr() + n0 * esz,
+                               n_frames=frames, frame_stride_px=tiler.cap * w, d_counters=counters.data_ptr(),
+                               stream=stream.cuda_stream, fudge=1e-3, bounces=args.bounces, rows=tiler.rows)
+        if events is not None:
+            e1.record(stream)
+            events.append((e0, e1))
         tiler.gather(slot)  # asynchronous: overlaps with the next step's rendering
 
     def barrier():
@@ -164,6 +176,7 @@ def main():
         value = total_rays / dt_max / 1e6
         # ---- roofline of the dominant (only) kernel, per launch ----
         alg_bytes, alg_rays = ds.algorithmic_bytes(bounces=args.bounces, rows=tiler.rows)
+        alg_bytes, alg_rays = alg_bytes * frames, alg_rays * frames  # one launch renders `frames` frames
         achieved = alg_bytes / (kern_avg * 1e-3) / 1e9 if kern_avg > 0 else 0.0
         traffic = None
         tj = args.traffic_json or os.path.join(ROOT, "profiles", "traffic.json")

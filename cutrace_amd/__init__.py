@@ -196,6 +196,24 @@ class DeviceScene:
         if st:
             raise RuntimeError(f"ctr_render_device failed ({st}): {L.ctr_last_error().decode()}")
 
+    def set_cameras(self, cams):
+        """Upload a camera path (list of _lib.Camera, same w/h): frames of ctr_render_device_batch."""
+        arr = (Camera * len(cams))(*cams)
+        st = _lib.hip_lib().ctr_scene_set_cameras(self._h, arr, len(cams))
+        if st:
+            raise RuntimeError(f"ctr_scene_set_cameras failed: {_lib.hip_lib().ctr_last_error().decode()}")
+        self.n_cams = len(cams)
+
+    def render_device_batch(self, d_depth, d_color, d_normal, n_frames, frame_stride_px, first_frame=0, d_counters=0,
+                            stream=0, fudge=1e-3, bounces=5, rows=None):
+        """n_frames frames in ONE launch (ctr_render_device_batch)."""
+        L = _lib.hip_lib()
+        r = make_rows(self.h, rows)
+        st = L.ctr_render_device_batch(self._h, C.c_float(fudge), bounces, C.byref(r), first_frame, n_frames,
+                                       frame_stride_px, d_depth, d_color, d_normal, d_counters, stream)
+        if st:
+            raise RuntimeError(f"ctr_render_device_batch failed ({st}): {L.ctr_last_error().decode()}")
+
     def algorithmic_bytes(self, fudge=1e-3, bounces=5, rows=None):
         L = _lib.hip_lib()
         r = make_rows(self.h, rows)

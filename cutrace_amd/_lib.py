@@ -71,6 +71,7 @@ HOST_SYMBOLS = [
 HIP_SYMBOLS = [
     "ctr_abi_version", "ctr_last_error", "ctr_device_count", "ctr_scene_create", "ctr_scene_destroy",
     "ctr_scene_size", "ctr_scene_set_size", "ctr_render", "ctr_render_device", "ctr_set_variant",
+    "ctr_scene_set_cameras", "ctr_render_device_batch",
     "ctr_algorithmic_bytes",
 ]
 
@@ -133,6 +134,9 @@ def hip_lib():
         L.ctr_render_device.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
         L.ctr_set_variant.argtypes = [C.c_void_p, C.c_uint32]
+        L.ctr_scene_set_cameras.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32]
+        L.ctr_render_device_batch.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.c_uint32, C.c_uint32,
+                                              C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ctr_algorithmic_bytes.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]
         _hip = L

@@ -47,6 +47,18 @@ inline f3 cross(f3 a, f3 o) { return {a.y * o.z - a.z * o.y, a.z * o.x - a.x * o
 
 constexpr uint32_t BVH_LEAF = 4;          // triangles per BVH leaf
 
+DCam to_dcam(const ctr_camera &c) {
+  DCam cam{};
+  cam.pos[0] = c.pos.x; cam.pos[1] = c.pos.y; cam.pos[2] = c.pos.z;
+  cam.up[0] = c.up.x; cam.up[1] = c.up.y; cam.up[2] = c.up.z;
+  cam.forward[0] = c.forward.x; cam.forward[1] = c.forward.y; cam.forward[2] = c.forward.z;
+  cam.right[0] = c.right.x; cam.right[1] = c.right.y; cam.right[2] = c.right.z;
+  cam.ambient = c.ambient;
+  cam.w = (uint32_t)c.w;
+  cam.h = (uint32_t)c.h;
+  return cam;
+}
+
 void make_tri(const ctr_vec3 &p1, const ctr_vec3 &p2, const ctr_vec3 &p3, uint32_t orig, DTri &T, float *gn) {
   f3 a = sub(p2, p1), b = sub(p2, p3);  // default_schema.hpp:58
   T.ax = a.x; T.ay = a.y; T.az = a.z;
@@ -84,7 +96,9 @@ struct ctr_scene {
   bool has_mesh = false;
   bool all_opaque = true;
   bool need_cold = false;
-  DCam cam{};
+  DCam cam{};                 // camera 0 (image size of every camera)
+  DCam *d_cams = nullptr;     // device camera array (>= 1 entry)
+  uint32_t n_cams = 0;
   uint32_t user_variant = CTR_VAR_AUTO;
   // cached device outputs for the host-buffer form
   float *d_depth = nullptr, *d_color = nullptr, *d_normal = nullptr;
@@ -157,7 +171,12 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.n_mat = s->n_mat;
   L.has_mesh = s->has_mesh ? 1u : 0u;
   L.need_cold_frames = s->need_cold ? 1u : 0u;
-  L.cam = s->cam;
+  L.cams = s->d_cams;
+  L.w = s->cam.w;
+  L.h = s->cam.h;
+  L.first_frame = 0;
+  L.n_frames = 1;
+  L.frame_stride_px = 0;
 }
 
 int check_args(const ctr_scene *s, int bounces) {
@@ -315,15 +334,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->has_mesh = has_mesh;
   s->all_opaque = all_opaque;
   s->need_cold = need_cold;
-  const ctr_camera &c = d->cam;
-  DCam cam{};
-  cam.pos[0] = c.pos.x; cam.pos[1] = c.pos.y; cam.pos[2] = c.pos.z;
-  cam.up[0] = c.up.x; cam.up[1] = c.up.y; cam.up[2] = c.up.z;
-  cam.forward[0] = c.forward.x; cam.forward[1] = c.forward.y; cam.forward[2] = c.forward.z;
-  cam.right[0] = c.right.x; cam.right[1] = c.right.y; cam.right[2] = c.right.z;
-  cam.ambient = c.ambient;
-  cam.w = (uint32_t)c.w;
-  cam.h = (uint32_t)c.h;
+  DCam cam = to_dcam(d->cam);
   s->cam = cam;
 
   auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
@@ -340,19 +351,44 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
       (er = upload((void **)&s->d_gnorm, gn.data(), gn.size() * sizeof(float))) != hipSuccess ||
       (er = upload((void **)&s->d_lights, lights.data(), lights.size() * sizeof(DLight))) != hipSuccess ||
       (er = upload((void **)&s->d_mats, mats.data(), mats.size() * sizeof(DMat))) != hipSuccess ||
+      (er = upload((void **)&s->d_cams, &s->cam, sizeof(DCam))) != hipSuccess ||
       (er = hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
       (er = hipEventCreate(&s->ev0)) != hipSuccess || (er = hipEventCreate(&s->ev1)) != hipSuccess) {
     ctr_scene_destroy(s);
     return hip_fail(er, "scene upload");
   }
+  s->n_cams = 1;
   *out = s;
+  return CTR_OK;
+}
+
+int ctr_scene_set_cameras(ctr_scene *s, const ctr_camera *cams, uint32_t n) {
+  if (!s || !cams || n == 0) return fail(CTR_E_INVALID, "ctr_scene_set_cameras: bad argument");
+  std::vector<DCam> dc(n);
+  for (uint32_t i = 0; i < n; i++) {
+    if (cams[i].w != cams[0].w || cams[i].h != cams[0].h)
+      return fail(CTR_E_INVALID, "ctr_scene_set_cameras: all cameras of a batch must share width and height");
+    dc[i] = to_dcam(cams[i]);
+  }
+  if (dc[0].w == 0 || dc[0].h == 0) return fail(CTR_E_INVALID, "camera has zero width or height");
+  std::lock_guard<std::mutex> lk(s->mtx);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());  // no launch may still be reading the old array
+  DCam *nd = nullptr;
+  HIP_TRY(hipMalloc((void **)&nd, sizeof(DCam) * n));
+  hipError_t e = hipMemcpy(nd, dc.data(), sizeof(DCam) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(nd); return hip_fail(e, "camera upload"); }
+  if (s->d_cams) (void)hipFree(s->d_cams);
+  s->d_cams = nd;
+  s->n_cams = n;
+  s->cam = dc[0];
   return CTR_OK;
 }
 
 void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void *p : {(void *)s->d_objs, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats,
+  for (void *p : {(void *)s->d_objs, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
                   (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters})
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -369,6 +405,13 @@ int ctr_scene_size(const ctr_scene *s, uint64_t *w, uint64_t *h) {
 
 int ctr_scene_set_size(ctr_scene *s, uint64_t w, uint64_t h) {
   if (!s || w == 0 || h == 0 || w > 0x7FFFFFFFull || h > 0x7FFFFFFFull) return fail(CTR_E_INVALID, "bad size");
+  std::lock_guard<std::mutex> lk(s->mtx);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<DCam> dc(s->n_cams);
+  HIP_TRY(hipMemcpy(dc.data(), s->d_cams, sizeof(DCam) * s->n_cams, hipMemcpyDeviceToHost));
+  for (DCam &c : dc) { c.w = (uint32_t)w; c.h = (uint32_t)h; }
+  HIP_TRY(hipMemcpy(s->d_cams, dc.data(), sizeof(DCam) * s->n_cams, hipMemcpyHostToDevice));
   s->cam.w = (uint32_t)w;
   s->cam.h = (uint32_t)h;
   return CTR_OK;
@@ -380,14 +423,22 @@ int ctr_set_variant(ctr_scene *s, uint32_t bits) {
   return CTR_OK;
 }
 
-int ctr_render_device(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, void *d_depth, void *d_color3,
-                      void *d_normal3, void *d_counters, void *hip_stream) {
+int ctr_render_device_batch(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, uint32_t first_frame,
+                            uint32_t n_frames, uint64_t frame_stride_px, void *d_depth, void *d_color3,
+                            void *d_normal3, void *d_counters, void *hip_stream) {
   int st = check_args(s, bounces);
   if (st) return st;
   if (!d_depth || !d_color3 || !d_normal3) return fail(CTR_E_INVALID, "null output buffer");
+  if (n_frames == 0 || first_frame >= s->n_cams || n_frames > s->n_cams - first_frame)
+    return fail(CTR_E_INVALID, "frame range exceeds the cameras set with ctr_scene_set_cameras");
   RenderLaunch L{};
   fill_launch(s, L);
   if ((st = make_rows(s, rows, L.rows))) return st;
+  if (n_frames > 1 && frame_stride_px < (uint64_t)L.rows.n_rows * s->cam.w)
+    return fail(CTR_E_INVALID, "frame_stride_px smaller than one frame's rows");
+  L.first_frame = first_frame;
+  L.n_frames = n_frames;
+  L.frame_stride_px = frame_stride_px;
   L.fudge = fudge;
   L.bounces = bounces;
   L.depth = (float *)d_depth;
@@ -398,6 +449,11 @@ int ctr_render_device(ctr_scene *s, float fudge, int bounces, const ctr_rows *ro
   int e = ctr_launch_render(L, hip_stream);
   if (e) return hip_fail((hipError_t)e, "render kernel launch");
   return CTR_OK;
+}
+
+int ctr_render_device(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, void *d_depth, void *d_color3,
+                      void *d_normal3, void *d_counters, void *hip_stream) {
+  return ctr_render_device_batch(s, fudge, bounces, rows, 0, 1, 0, d_depth, d_color3, d_normal3, d_counters, hip_stream);
 }
 
 static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,

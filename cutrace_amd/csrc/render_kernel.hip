@@ -105,7 +105,10 @@ struct KArgs {
   const CADDR DLight *lights;
   const CADDR DMat *mats;
   uint32_t n_obj, n_light;
-  DCam cam;
+  const CADDR DCam *cams;      // one camera per frame of the batch (all w x h)
+  uint32_t w, h;
+  uint32_t first_frame, n_frames;
+  uint64_t frame_stride_px;    // pixels between consecutive frames in the output buffers
   DRows rows;
   float fudge;
   int bounces;
@@ -132,13 +135,17 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
 
-  const uint32_t w = A.cam.w, h = A.cam.h;
+  const uint32_t w = A.w, h = A.h;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * WAVES_PER_WG) + (threadIdx.x >> 6);
   const uint32_t tiles_x = (w + TW - 1) / TW;
   const uint32_t tiles_y = (A.rows.n_rows + TH - 1) / TH;
-  if (wave >= tiles_x * tiles_y) return;  // whole wave exits together
-  const uint32_t tx = wave % tiles_x, ty = wave / tiles_x;
+  const uint32_t tiles_frame = tiles_x * tiles_y;
+  if (wave >= tiles_frame * A.n_frames) return;  // whole wave exits together
+  // batch of frames (a camera path): frame-major waves, one camera per frame (wave-uniform)
+  const uint32_t frame = wave / tiles_frame, tile = wave - frame * tiles_frame;
+  const CADDR DCam &cam = A.cams[A.first_frame + frame];
+  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
   const uint32_t x_id = tx * TW + (lane % TW);
   const uint32_t k_row = ty * TH + (lane / TW);  // local (compact) row
   const bool in_image = x_id < w && k_row < A.rows.n_rows;
@@ -149,22 +156,22 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     uint32_t j = k_row / A.rows.block_rows;
     y_id = (A.rows.first_block + j * A.rows.n_parts) * A.rows.block_rows + (k_row % A.rows.block_rows);
   }
-  const size_t px_id = (size_t)k_row * w + x_id;  // kernel.hpp:54 on the compact buffer
+  const size_t px_id = (size_t)frame * A.frame_stride_px + (size_t)k_row * w + x_id;  // kernel.hpp:54, compact buffer
 
   // ---- cam::get_ray, default_schema.hpp:376-386 ----
   V3 ro, rd;
   {
     const float fw = (float)w, fh = (float)h;
     const float aspect = fw / fh;
-    const V3 right = mk(A.cam.right[0], A.cam.right[1], A.cam.right[2]);
-    const V3 up = mk(A.cam.up[0], A.cam.up[1], A.cam.up[2]);
-    const V3 fwd = mk(A.cam.forward[0], A.cam.forward[1], A.cam.forward[2]);
+    const V3 right = mk(cam.right[0], cam.right[1], cam.right[2]);
+    const V3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
+    const V3 fwd = mk(cam.forward[0], cam.forward[1], cam.forward[2]);
     V3 x_v = vscale(right, (((float)x_id / fw) - 0.5f) * aspect);
     V3 y_v = vscale(up, 0.5f - ((float)y_id / fh));
-    ro = mk(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
+    ro = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
     rd = vnormalized(vadd(vadd(x_v, y_v), fwd));
   }
-  const float ambient = A.cam.ambient;
+  const float ambient = cam.ambient;
 
   // ---- per-lane state machine ----
   int mode = in_image ? M_RADIANCE : M_DONE;
@@ -602,7 +609,12 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.mats = (const CADDR DMat *)L.mats;
   A.n_obj = L.n_obj;
   A.n_light = L.n_light;
-  A.cam = L.cam;
+  A.cams = (const CADDR DCam *)L.cams;
+  A.w = L.w;
+  A.h = L.h;
+  A.first_frame = L.first_frame;
+  A.n_frames = L.n_frames;
+  A.frame_stride_px = L.frame_stride_px;
   A.rows = L.rows;
   A.fudge = L.fudge;
   A.bounces = L.bounces;
@@ -610,8 +622,9 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.nf = L.need_cold_frames ? 12u : 6u;
   A.frames = (uint32_t)(L.bounces > 0 ? L.bounces : 1);
   const size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
-  const uint32_t tiles_x = (L.cam.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
-  const uint64_t waves = (uint64_t)tiles_x * tiles_y;
+  const uint32_t tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
+  const uint64_t waves = (uint64_t)tiles_x * tiles_y * L.n_frames;
+  if (waves > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
   if (waves == 0) return 0;
   const uint32_t grid = (uint32_t)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
   hipLaunchKernelGGL(render_kernel<KV>, dim3(grid), dim3(WG_THREADS), lds_bytes, stream, A, L.depth, L.color, L.normal,

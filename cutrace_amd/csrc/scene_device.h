@@ -102,7 +102,10 @@ struct RenderLaunch {
   uint32_t n_obj, n_light, n_mat;
   uint32_t has_mesh;
   uint32_t need_cold_frames;  // some material both reflects and transmits (>= 1e-6 each)
-  DCam cam;
+  const DCam *cams;           // device array, one camera per frame
+  uint32_t w, h;
+  uint32_t first_frame, n_frames;
+  uint64_t frame_stride_px;
   DRows rows;
   float fudge;
   int bounces;

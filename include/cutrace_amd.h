@@ -172,6 +172,17 @@ int ctr_render_device(ctr_scene *scene, float fudge, int bounces, const ctr_rows
                       void *d_depth, void *d_color3, void *d_normal3,
                       void *d_counters, void *hip_stream);
 
+/* Batch form: a sequence of frames of the same scene (a camera path) in ONE launch, so that a
+ * rank that owns only 1/N of each frame's rows still fills the chip.  Cameras are uploaded once
+ * with ctr_scene_set_cameras (all must share width/height; camera 0 replaces the scene's own);
+ * frame f of the batch uses camera first_frame+f and writes its rows at pixel offset
+ * f*frame_stride_px of the three buffers (same compact row layout as ctr_render_device). */
+int ctr_scene_set_cameras(ctr_scene *scene, const ctr_camera *cams, uint32_t n_cams);
+int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
+                            uint32_t first_frame, uint32_t n_frames, uint64_t frame_stride_px,
+                            void *d_depth, void *d_color3, void *d_normal3,
+                            void *d_counters, void *hip_stream);
+
 /* Kernel variant selection (tuning / ablation; default picks the fastest
  * variant that is exact for the scene).  Bits: */
 #define CTR_VAR_AUTO 0u

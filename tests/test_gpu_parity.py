@@ -166,6 +166,48 @@ def test_device_buffer_form_with_torch(gpu):
     assert int(counters[0].item()) == ref["ray_count"]
 
 
+def test_batch_launch_equals_single_frames(gpu):
+    """ctr_render_device_batch: a camera path in one launch == the frames rendered one by one."""
+    import ctypes as C
+    import torch
+    from cutrace_amd import _lib
+    s = load_scene(gpu, "bunny", 96, 56)
+    cam0 = s.desc.contents.cam
+    cams = []
+    for i in range(3):
+        c = gpu.Camera()
+        C.memmove(C.byref(c), C.byref(cam0), C.sizeof(gpu.Camera))
+        _lib.host_lib().ctr_camera_look_at(C.byref(c), _lib.Vec3(1.0 + 0.2 * i, 0.1 * i, 2.0), _lib.Vec3(0, 1, 0),
+                                           _lib.Vec3(-0.92388, 0, -0.38268))
+        cams.append(c)
+    singles = []
+    for c in cams:
+        ds1 = gpu.DeviceScene(s)
+        ds1.set_cameras([c])
+        singles.append(ds1.render())
+    ds = gpu.DeviceScene(s)
+    ds.set_cameras(cams)
+    dev = torch.device("cuda:0")
+    rows = (0, 56, 8, 1, 2)  # this "rank" owns every second 8-row block
+    ys = [y for y in range(56) if (y // 8) % 2 == 1]
+    cap = len(ys) + 3        # padded frame stride, like the multi-GPU tiler
+    depth = torch.zeros(3 * cap * 96, dtype=torch.float32, device=dev)
+    color = torch.zeros(3 * cap * 96 * 3, dtype=torch.float32, device=dev)
+    normal = torch.zeros(3 * cap * 96 * 3, dtype=torch.float32, device=dev)
+    counters = torch.zeros(16, dtype=torch.int64, device=dev)
+    ds.render_device_batch(depth.data_ptr(), color.data_ptr(), normal.data_ptr(), n_frames=3,
+                           frame_stride_px=cap * 96, d_counters=counters.data_ptr(), rows=rows)
+    torch.cuda.synchronize()
+    d = depth.cpu().numpy().reshape(3, cap, 96)
+    c = color.cpu().numpy().reshape(3, cap, 96, 3)
+    for f in range(3):
+        assert same_bits(d[f, :len(ys)], singles[f]["depth"][ys]), f
+        assert same_bits(c[f, :len(ys)], singles[f]["color"][ys]), f
+        assert not d[f, len(ys):].any()  # padding rows untouched
+    with pytest.raises(RuntimeError):
+        ds.render_device_batch(depth.data_ptr(), color.data_ptr(), normal.data_ptr(), n_frames=4, frame_stride_px=cap * 96)
+
+
 def test_bad_arguments_fail_loudly(gpu):
     s = load_scene(gpu, "triangle")
     ds = gpu.DeviceScene(s)
