@@ -47,6 +47,8 @@ def parse_args():
     p.add_argument("--variant", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-div", type=int, default=0, help="CPU baseline renders 1/div of the row blocks (0=auto)")
+    p.add_argument("--of", type=int, default=0, help="diagnostic: time the tiled batch render of one rank of N (no gather)")
+    p.add_argument("--as-rank", type=int, default=0)
     p.add_argument("--traffic-json", default="", help="optional JSON with PMC-derived HBM bytes per launch")
     return p.parse_args()
 
@@ -105,7 +107,15 @@ def main():
     if args.variant:
         ds.set_variant(args.variant)
     frames = world if args.scaling == "weak" else 1
-    tiler = FrameTiler(w, h, frames, rank, world, dev)
+    sim = args.of if (world == 1 and args.of > 1) else 0
+    if sim:  # one process plays rank `as_rank` of `of` ranks: same launches, no collective
+        frames = sim if args.scaling == "weak" else 1
+        tiler = FrameTiler(w, h, frames, args.as_rank, sim, dev)
+        tiler.gather = lambda slot: None
+        tiler.begin = lambda slot: None
+        tiler.finish = lambda: None
+    else:
+        tiler = FrameTiler(w, h, frames, rank, world, dev)
     if frames > 1:
         import ctypes
         cam0 = hs.desc.contents.cam
@@ -133,7 +143,8 @@ def main():
         # ONE launch renders this rank's rows of all `frames` frames of the step (camera path batch)
         ds.render_device_batch(buf.data_ptr() + d0 * esz, buf.data_ptr() + c0 * esz, buf.data_ptr() + n0 * esz,
                                n_frames=frames, frame_stride_px=tiler.cap * w, d_counters=counters.data_ptr(),
-                               stream=stream.cuda_stream, fudge=1e-3, bounces=args.bounces, rows=tiler.rows)
+                               stream=stream.cuda_stream, fudge=1e-3, bounces=args.bounces, rows=tiler.rows,
+                               part_stride=tiler.part_stride)
         if events is not None:
             e1.record(stream)
             events.append((e0, e1))

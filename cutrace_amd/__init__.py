@@ -205,12 +205,12 @@ class DeviceScene:
         self.n_cams = len(cams)
 
     def render_device_batch(self, d_depth, d_color, d_normal, n_frames, frame_stride_px, first_frame=0, d_counters=0,
-                            stream=0, fudge=1e-3, bounces=5, rows=None):
+                            stream=0, fudge=1e-3, bounces=5, rows=None, part_stride=0):
         """n_frames frames in ONE launch (ctr_render_device_batch)."""
         L = _lib.hip_lib()
         r = make_rows(self.h, rows)
         st = L.ctr_render_device_batch(self._h, C.c_float(fudge), bounces, C.byref(r), first_frame, n_frames,
-                                       frame_stride_px, d_depth, d_color, d_normal, d_counters, stream)
+                                       frame_stride_px, part_stride, d_depth, d_color, d_normal, d_counters, stream)
         if st:
             raise RuntimeError(f"ctr_render_device_batch failed ({st}): {L.ctr_last_error().decode()}")
 

@@ -136,7 +136,7 @@ def hip_lib():
         L.ctr_set_variant.argtypes = [C.c_void_p, C.c_uint32]
         L.ctr_scene_set_cameras.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32]
         L.ctr_render_device_batch.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.c_uint32, C.c_uint32,
-                                              C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                              C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ctr_algorithmic_bytes.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]
         _hip = L

@@ -136,6 +136,8 @@ int make_rows(const ctr_scene *s, const ctr_rows *rin, DRows &R) {
   if (r.n_parts > 1 && (r.row_begin % r.block_rows) != 0)
     return fail(CTR_E_INVALID, "ctr_rows: row_begin must be a multiple of block_rows when n_parts > 1");
   R.row_begin = (uint32_t)r.row_begin;
+  R.row_end = (uint32_t)r.row_end;
+  R.part_stride = 0;
   R.block_rows = (uint32_t)r.block_rows;
   R.part = r.part;
   R.n_parts = r.n_parts;
@@ -424,8 +426,8 @@ int ctr_set_variant(ctr_scene *s, uint32_t bits) {
 }
 
 int ctr_render_device_batch(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, uint32_t first_frame,
-                            uint32_t n_frames, uint64_t frame_stride_px, void *d_depth, void *d_color3,
-                            void *d_normal3, void *d_counters, void *hip_stream) {
+                            uint32_t n_frames, uint64_t frame_stride_px, uint32_t part_stride, void *d_depth,
+                            void *d_color3, void *d_normal3, void *d_counters, void *hip_stream) {
   int st = check_args(s, bounces);
   if (st) return st;
   if (!d_depth || !d_color3 || !d_normal3) return fail(CTR_E_INVALID, "null output buffer");
@@ -434,6 +436,19 @@ int ctr_render_device_batch(ctr_scene *s, float fudge, int bounces, const ctr_ro
   RenderLaunch L{};
   fill_launch(s, L);
   if ((st = make_rows(s, rows, L.rows))) return st;
+  if (part_stride && L.rows.n_parts > 1) {
+    // parts rotate: size the per-frame tile grid for the largest part
+    L.rows.part_stride = part_stride % L.rows.n_parts;
+    uint32_t cap = 0;
+    for (uint32_t p = 0; p < L.rows.n_parts; p++) {
+      ctr_rows rp = *rows;
+      rp.part = p;
+      DRows tmp{};
+      if ((st = make_rows(s, &rp, tmp))) return st;
+      cap = tmp.n_rows > cap ? tmp.n_rows : cap;
+    }
+    L.rows.n_rows = cap;
+  }
   if (n_frames > 1 && frame_stride_px < (uint64_t)L.rows.n_rows * s->cam.w)
     return fail(CTR_E_INVALID, "frame_stride_px smaller than one frame's rows");
   L.first_frame = first_frame;
@@ -453,7 +468,7 @@ int ctr_render_device_batch(ctr_scene *s, float fudge, int bounces, const ctr_ro
 
 int ctr_render_device(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, void *d_depth, void *d_color3,
                       void *d_normal3, void *d_counters, void *hip_stream) {
-  return ctr_render_device_batch(s, fudge, bounces, rows, 0, 1, 0, d_depth, d_color3, d_normal3, d_counters, hip_stream);
+  return ctr_render_device_batch(s, fudge, bounces, rows, 0, 1, 0, 0, d_depth, d_color3, d_normal3, d_counters, hip_stream);
 }
 
 static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,

@@ -55,6 +55,9 @@ namespace {
 #ifndef CTR_WAVES_PER_WG
 #define CTR_WAVES_PER_WG 1
 #endif
+#ifndef CTR_TILE_STRIDE
+#define CTR_TILE_STRIDE 1
+#endif
 #ifndef CTR_MIN_WAVES_EU
 #define CTR_MIN_WAVES_EU 1
 #endif
@@ -109,6 +112,7 @@ struct KArgs {
   uint32_t w, h;
   uint32_t first_frame, n_frames;
   uint64_t frame_stride_px;    // pixels between consecutive frames in the output buffers
+  uint32_t tile_mul;           // multiplier coprime to the tiles per frame (strided tile order)
   DRows rows;
   float fudge;
   int bounces;
@@ -143,19 +147,31 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   const uint32_t tiles_frame = tiles_x * tiles_y;
   if (wave >= tiles_frame * A.n_frames) return;  // whole wave exits together
   // batch of frames (a camera path): frame-major waves, one camera per frame (wave-uniform)
-  const uint32_t frame = wave / tiles_frame, tile = wave - frame * tiles_frame;
+  const uint32_t frame = wave / tiles_frame;
+#if CTR_TILE_STRIDE
+  // visit the tiles of a frame in a strided order so that costly neighbouring tiles (the mesh)
+  // are not all resident at the same time
+  const uint32_t tile = (uint32_t)(((uint64_t)(wave - frame * tiles_frame) * A.tile_mul) % tiles_frame);
+#else
+  const uint32_t tile = wave - frame * tiles_frame;
+#endif
   const CADDR DCam &cam = A.cams[A.first_frame + frame];
   const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
   const uint32_t x_id = tx * TW + (lane % TW);
   const uint32_t k_row = ty * TH + (lane / TW);  // local (compact) row
-  const bool in_image = x_id < w && k_row < A.rows.n_rows;
-  // local row -> global image row (interleaved row blocks, see ctr_rows)
+  // local row -> global image row (interleaved row blocks, see ctr_rows).  In a batch the part a
+  // rank renders may rotate from frame to frame (part_stride), which balances ranks whose row
+  // blocks differ in cost.
   uint32_t y_id;
   if (A.rows.n_parts <= 1) y_id = A.rows.row_begin + k_row;
   else {
-    uint32_t j = k_row / A.rows.block_rows;
-    y_id = (A.rows.first_block + j * A.rows.n_parts) * A.rows.block_rows + (k_row % A.rows.block_rows);
+    const uint32_t part_f = (A.rows.part + frame * A.rows.part_stride) % A.rows.n_parts;
+    const uint32_t b0 = A.rows.row_begin / A.rows.block_rows;
+    const uint32_t first = b0 + ((part_f + A.rows.n_parts - (b0 % A.rows.n_parts)) % A.rows.n_parts);
+    const uint32_t j = k_row / A.rows.block_rows;
+    y_id = (first + j * A.rows.n_parts) * A.rows.block_rows + (k_row % A.rows.block_rows);
   }
+  const bool in_image = x_id < w && k_row < A.rows.n_rows && y_id < A.rows.row_end;
   const size_t px_id = (size_t)frame * A.frame_stride_px + (size_t)k_row * w + x_id;  // kernel.hpp:54, compact buffer
 
   // ---- cam::get_ray, default_schema.hpp:376-386 ----
@@ -624,6 +640,15 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   const size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
   const uint32_t tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
   const uint64_t waves = (uint64_t)tiles_x * tiles_y * L.n_frames;
+  {
+    // a multiplier near tiles/golden-ratio, coprime to the tile count
+    const uint32_t n = tiles_x * tiles_y;
+    uint32_t m = (uint32_t)(n * 0.6180339887) | 1u;
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
+    while (n > 1 && gcd(m, n) != 1) m += 2;
+    A.tile_mul = n > 1 ? m % n : 0;
+    if (n > 1 && A.tile_mul == 0) A.tile_mul = 1;
+  }
   if (waves > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
   if (waves == 0) return 0;
   const uint32_t grid = (uint32_t)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);

@@ -86,7 +86,9 @@ enum : uint32_t {
 
 struct DRows {
   uint32_t row_begin;   // first global row of this call's selection
-  uint32_t n_rows;      // number of selected (local) rows
+  uint32_t row_end;     // one past the last global row
+  uint32_t part_stride; // batch: frame f renders part (part + f*part_stride) % n_parts
+  uint32_t n_rows;      // local rows per frame (the largest part's row count when parts rotate)
   uint32_t block_rows;  // interleave block height
   uint32_t part, n_parts;
   uint32_t first_block; // index of the first selected block

@@ -35,11 +35,14 @@ def max_part_rows(h, n_parts, block_rows=BLOCK_ROWS):
 class FrameTiler:
     """Buffers and index tables for rendering `frames` frames of w x h per step on `world` ranks."""
 
-    def __init__(self, w, h, frames, rank, world, device, block_rows=BLOCK_ROWS, slots=2):
+    def __init__(self, w, h, frames, rank, world, device, block_rows=BLOCK_ROWS, slots=2, rotate=True):
         self.w, self.h, self.frames, self.rank, self.world = w, h, frames, rank, world
         self.device = torch.device(device)
         self.block_rows = block_rows
         self.rows = (0, h, block_rows, rank, world) if world > 1 else None
+        # frame f of a step is rendered by this rank for part (rank + f*part_stride) % world: over a
+        # batch every rank sees every row block, so ranks with costly blocks do not lag
+        self.part_stride = 1 if (rotate and world > 1 and frames > 1) else 0
         self.my_rows = part_rows(h, rank, world, block_rows) if world > 1 else list(range(h))
         self.cap = max_part_rows(h, world, block_rows) if world > 1 else h  # padded rows per rank
         self.slots = slots if world > 1 else 1
@@ -59,20 +62,32 @@ class FrameTiler:
             if world > 1:
                 self.gathered = [torch.zeros(world, 7 * per, dtype=f32, device=self.device) for _ in range(self.slots)]
                 # position of global row y inside the (world*cap) padded row axis
-                perm = torch.empty(h, dtype=torch.int64)
-                for p in range(world):
-                    for k, y in enumerate(part_rows(h, p, world, block_rows)):
-                        perm[y] = p * self.cap + k
-                self.perm = perm.to(self.device)
+                perm = torch.empty(frames, h, dtype=torch.int64)
+                for f in range(frames):
+                    for p in range(world):
+                        r = (p - f * self.part_stride) % world  # the rank that rendered part p of frame f
+                        for k, y in enumerate(part_rows(h, p, world, block_rows)):
+                            perm[f, y] = (f * world + r) * self.cap + k
+                self.perm = perm.reshape(-1).to(self.device)
                 if self.is_cuda:
                     self.side = torch.cuda.Stream(device=self.device)
             self.final = dict(depth=torch.zeros(frames, h, w, dtype=f32, device=self.device),
                               color=torch.zeros(frames, h, w, 3, dtype=f32, device=self.device),
                               normal=torch.zeros(frames, h, w, 3, dtype=f32, device=self.device))
 
+    def frame_part(self, frame):
+        return (self.rank + frame * self.part_stride) % self.world
+
+    def frame_rows(self, frame):
+        """ctr_rows tuple for what this rank renders of `frame`."""
+        if self.world == 1:
+            return None
+        return (0, self.h, self.block_rows, self.frame_part(frame), self.world)
+
     def views(self, slot, frame):
         """Compact (rows_local x w) views of this rank's buffers for one frame of one slot."""
-        n, w, cap = len(self.my_rows), self.w, self.cap
+        n = len(part_rows(self.h, self.frame_part(frame), self.world, self.block_rows)) if self.world > 1 else self.h
+        w, cap = self.w, self.cap
         d0, c0, n0, _ = self.sec
         buf = self.local[slot]
         d = buf[d0 + frame * cap * w: d0 + frame * cap * w + n * w]
@@ -135,9 +150,10 @@ class FrameTiler:
         W, F, cap, w = self.world, self.frames, self.cap, self.w
         d0, c0, n0, e = self.sec
         g = self.gathered[slot]
-        dep = g[:, d0:c0].view(W, F, cap, w).permute(1, 0, 2, 3).reshape(F, W * cap, w)
-        col = g[:, c0:n0].view(W, F, cap, w, 3).permute(1, 0, 2, 3, 4).reshape(F, W * cap, w, 3)
-        nor = g[:, n0:e].view(W, F, cap, w, 3).permute(1, 0, 2, 3, 4).reshape(F, W * cap, w, 3)
-        torch.index_select(dep, 1, self.perm, out=self.final["depth"])
-        torch.index_select(col, 1, self.perm, out=self.final["color"])
-        torch.index_select(nor, 1, self.perm, out=self.final["normal"])
+        h = self.h
+        dep = g[:, d0:c0].view(W, F, cap, w).permute(1, 0, 2, 3).reshape(F * W * cap, w)
+        col = g[:, c0:n0].view(W, F, cap, w, 3).permute(1, 0, 2, 3, 4).reshape(F * W * cap, w, 3)
+        nor = g[:, n0:e].view(W, F, cap, w, 3).permute(1, 0, 2, 3, 4).reshape(F * W * cap, w, 3)
+        torch.index_select(dep, 0, self.perm, out=self.final["depth"].view(F * h, w))
+        torch.index_select(col, 0, self.perm, out=self.final["color"].view(F * h, w, 3))
+        torch.index_select(nor, 0, self.perm, out=self.final["normal"].view(F * h, w, 3))

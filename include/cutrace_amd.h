@@ -176,11 +176,15 @@ int ctr_render_device(ctr_scene *scene, float fudge, int bounces, const ctr_rows
  * rank that owns only 1/N of each frame's rows still fills the chip.  Cameras are uploaded once
  * with ctr_scene_set_cameras (all must share width/height; camera 0 replaces the scene's own);
  * frame f of the batch uses camera first_frame+f and writes its rows at pixel offset
- * f*frame_stride_px of the three buffers (same compact row layout as ctr_render_device). */
+ * f*frame_stride_px of the three buffers (same compact row layout as ctr_render_device).
+ * part_stride != 0 rotates the row part from frame to frame: frame f renders part
+ * (rows->part + f*part_stride) % rows->n_parts — over a batch every rank then sees every row
+ * block, which evens out ranks whose blocks differ in cost.  frame_stride_px must then hold the
+ * largest part. */
 int ctr_scene_set_cameras(ctr_scene *scene, const ctr_camera *cams, uint32_t n_cams);
 int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
                             uint32_t first_frame, uint32_t n_frames, uint64_t frame_stride_px,
-                            void *d_depth, void *d_color3, void *d_normal3,
+                            uint32_t part_stride, void *d_depth, void *d_color3, void *d_normal3,
                             void *d_counters, void *hip_stream);
 
 /* Kernel variant selection (tuning / ablation; default picks the fastest

@@ -190,7 +190,7 @@ def test_batch_launch_equals_single_frames(gpu):
     dev = torch.device("cuda:0")
     rows = (0, 56, 8, 1, 2)  # this "rank" owns every second 8-row block
     ys = [y for y in range(56) if (y // 8) % 2 == 1]
-    cap = len(ys) + 3        # padded frame stride, like the multi-GPU tiler
+    cap = 32 + 3             # padded frame stride (largest part = 32 rows), like the multi-GPU tiler
     depth = torch.zeros(3 * cap * 96, dtype=torch.float32, device=dev)
     color = torch.zeros(3 * cap * 96 * 3, dtype=torch.float32, device=dev)
     normal = torch.zeros(3 * cap * 96 * 3, dtype=torch.float32, device=dev)
@@ -204,6 +204,16 @@ def test_batch_launch_equals_single_frames(gpu):
         assert same_bits(d[f, :len(ys)], singles[f]["depth"][ys]), f
         assert same_bits(c[f, :len(ys)], singles[f]["color"][ys]), f
         assert not d[f, len(ys):].any()  # padding rows untouched
+    # rotating parts: frame f renders part (1 + f) % 2
+    depth.zero_(); color.zero_()
+    ds.render_device_batch(depth.data_ptr(), color.data_ptr(), normal.data_ptr(), n_frames=3,
+                           frame_stride_px=cap * 96, rows=rows, part_stride=1)
+    torch.cuda.synchronize()
+    d = depth.cpu().numpy().reshape(3, cap, 96)
+    for f in range(3):
+        yf = [y for y in range(56) if (y // 8) % 2 == (1 + f) % 2]
+        assert same_bits(d[f, :len(yf)], singles[f]["depth"][yf]), f
+        assert not d[f, len(yf):].any()
     with pytest.raises(RuntimeError):
         ds.render_device_batch(depth.data_ptr(), color.data_ptr(), normal.data_ptr(), n_frames=4, frame_stride_px=cap * 96)
 

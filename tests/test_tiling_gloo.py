@@ -37,7 +37,7 @@ def _worker(rank, world, port, w, h, frames, steps, out_path):
         slot = step % tiler.slots
         tiler.begin(slot)
         for f in range(frames):
-            r = ca.oracle_render(s, bounces=2 + f, rows=tiler.rows, threads=2)  # frames differ by bounces
+            r = ca.oracle_render(s, bounces=2 + f, rows=tiler.frame_rows(f), threads=2)  # frames differ by bounces
             d, c, n = tiler.views(slot, f)
             d.copy_(torch.from_numpy(r["depth"]).reshape(-1))
             c.copy_(torch.from_numpy(r["color"]).reshape(-1))
