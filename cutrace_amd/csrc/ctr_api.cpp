@@ -45,7 +45,10 @@ struct f3 { float x, y, z; };
 inline f3 sub(ctr_vec3 a, ctr_vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline f3 cross(f3 a, f3 o) { return {a.y * o.z - a.z * o.y, a.z * o.x - a.x * o.z, a.x * o.y - a.y * o.x}; }
 
-constexpr uint32_t BVH_LEAF = 4;          // triangles per BVH leaf
+#ifndef CTR_BVH_LEAF
+#define CTR_BVH_LEAF 8
+#endif
+constexpr uint32_t BVH_LEAF = CTR_BVH_LEAF;  // triangles per BVH leaf
 
 DCam to_dcam(const ctr_camera &c) {
   DCam cam{};

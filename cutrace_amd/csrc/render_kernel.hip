@@ -43,6 +43,9 @@
 
 #define CADDR __attribute__((address_space(4)))
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
+#define INVB(m) __builtin_amdgcn_inverse_ballot_w64(m)   /* wave-uniform lane mask -> per-lane predicate */
+#define FCMP(a, b, pred) __builtin_amdgcn_fcmpf((a), (b), (pred))  /* v_cmp straight into a lane mask */
+enum { FC_OGT = 2, FC_OGE = 3, FC_OLT = 4, FC_OLE = 5 };          /* LLVM FCmp predicate numbers */
 
 namespace {
 
@@ -59,7 +62,7 @@ namespace {
 #define CTR_TILE_STRIDE 1
 #endif
 #ifndef CTR_MIN_WAVES_EU
-#define CTR_MIN_WAVES_EU 1
+#define CTR_MIN_WAVES_EU 4
 #endif
 constexpr int TW = CTR_TW, TH = CTR_TH;  // pixel tile of one wave (TW*TH == 64)
 static_assert(TW * TH == 64, "one wave = one TW x TH tile");
@@ -221,10 +224,13 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     float best = INFINITY;
     int bobj = -1, btri = -1;
     bool live = active;  // lanes still searching (any-hit mode retires occluded lanes)
-    V3 rinv = mk(0, 0, 0);
+    V3 rinv = mk(0, 0, 0);     // exact 1/dir (IEEE divisions), computed lazily: see the mesh branch
+    bool have_rinv = false;    // wave-uniform
+    V3 ria = mk(0, 0, 0), roi = mk(0, 0, 0);
     float cmax = 0.f;
     if (A.has_mesh) {
-      rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);  // default_schema.hpp:103
+      ria = mk(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));  // 1 ulp
+      roi = mk(ro.x * ria.x, ro.y * ria.y, ro.z * ria.z);  // box tests as fma(b, 1/d, -o/d)
       cmax = fmaxf(fmaxf(fabsf(rd.x), fabsf(rd.y)), fabsf(rd.z));
     }
 
@@ -235,41 +241,73 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       float cand = INFINITY;
       int ctri = -1;
       if (type == CTR_OBJ_MESH) {
-        // ---- mesh::bound_intersects, default_schema.hpp:99-114 (exact, per lane) ----
-        float tmin = 0.0f, tmax = INFINITY;
+        // Everything in this branch works on 64-bit lane masks (v_cmp results kept in SGPRs and
+        // combined on the scalar unit) instead of per-lane booleans.
+        typedef unsigned long long mask_t;
+        const mask_t live_m = BALLOT(live);
+        // ---- mesh::bound_intersects, default_schema.hpp:99-114 ----
+        // The reference's slab test needs three IEEE divisions (1/dir) per ray.  With 1-ulp
+        // reciprocals every t is within 3 ulp of the exact one and tmin/tmax are 1-Lipschitz in
+        // the t's, so lanes whose tmin/tmax differ by more than dl = 2^-20 * max|t| are decided
+        // without them; only borderline lanes (or NaN/inf: axis-parallel rays) take the exact path.
+        mask_t bb_m;
         {
-          float t1 = (O.f[0] - ro.x) * rinv.x, t2 = (O.f[3] - ro.x) * rinv.x;
-          tmin = smin(smax(t1, tmin), smax(t2, tmin));
-          tmax = smax(smin(t1, tmax), smin(t2, tmax));
-          t1 = (O.f[1] - ro.y) * rinv.y; t2 = (O.f[4] - ro.y) * rinv.y;
-          tmin = smin(smax(t1, tmin), smax(t2, tmin));
-          tmax = smax(smin(t1, tmax), smin(t2, tmax));
-          t1 = (O.f[2] - ro.z) * rinv.z; t2 = (O.f[5] - ro.z) * rinv.z;
-          tmin = smin(smax(t1, tmin), smax(t2, tmin));
-          tmax = smax(smin(t1, tmax), smin(t2, tmax));
+          const float a1x = (O.f[0] - ro.x) * ria.x, a2x = (O.f[3] - ro.x) * ria.x;
+          const float a1y = (O.f[1] - ro.y) * ria.y, a2y = (O.f[4] - ro.y) * ria.y;
+          const float a1z = (O.f[2] - ro.z) * ria.z, a2z = (O.f[5] - ro.z) * ria.z;
+          const float lo_a = fmaxf(fmaxf(fmaxf(fminf(a1x, a2x), fminf(a1y, a2y)), fminf(a1z, a2z)), 0.0f);
+          const float hi_a = fminf(fminf(fmaxf(a1x, a2x), fmaxf(a1y, a2y)), fmaxf(a1z, a2z));
+          const float tabs = fmaxf(fmaxf(fmaxf(fabsf(a1x), fabsf(a2x)), fmaxf(fabsf(a1y), fabsf(a2y))),
+                                   fmaxf(fabsf(a1z), fabsf(a2z)));
+          const float dl = tabs * 0x1p-20f;
+          const mask_t def_hit = FCMP(lo_a + dl, hi_a, FC_OLT);
+          const mask_t def_miss = FCMP(lo_a - dl, hi_a, FC_OGT);
+          const mask_t border = live_m & ~(def_hit | def_miss);
+          bb_m = live_m & def_hit;
+          if (border != 0ull) {
+            if (!have_rinv) {  // wave-uniform: the exact reciprocals are computed at most once per cast
+              rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);  // default_schema.hpp:103
+              have_rinv = true;
+            }
+            float tmin = 0.0f, tmax = INFINITY;
+            float t1 = (O.f[0] - ro.x) * rinv.x, t2 = (O.f[3] - ro.x) * rinv.x;
+            tmin = smin(smax(t1, tmin), smax(t2, tmin));
+            tmax = smax(smin(t1, tmax), smin(t2, tmax));
+            t1 = (O.f[1] - ro.y) * rinv.y; t2 = (O.f[4] - ro.y) * rinv.y;
+            tmin = smin(smax(t1, tmin), smax(t2, tmin));
+            tmax = smax(smin(t1, tmax), smin(t2, tmax));
+            t1 = (O.f[2] - ro.z) * rinv.z; t2 = (O.f[5] - ro.z) * rinv.z;
+            tmin = smin(smax(t1, tmin), smax(t2, tmin));
+            tmax = smax(smin(t1, tmax), smin(t2, tmax));
+            bb_m |= border & FCMP(tmin, tmax, FC_OLE);
+          }
         }
-        bool bb = live && (tmin <= tmax);
-        if (BALLOT(bb) == 0ull) continue;  // no lane of this wave needs the mesh
+        if (bb_m == 0ull) continue;  // no lane of this wave needs the mesh
+        const mask_t bb0_m = bb_m;
         const uint32_t beg = O.tri_begin, cnt = O.tri_count;
-        if (COUNT) n_aabb_tris += bb ? (unsigned long long)cnt : 0ull;
+        if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
         if (STATS) st[4]++;
         // ---- mesh::intersect, default_schema.hpp:125-144: smallest valid t, FIRST triangle in
         //      file order on ties (strict < over file order)  ==  lexicographic min of (t, orig) ----
         float mt = INFINITY;
         int mk_ = -1;
         uint32_t morig = 0xFFFFFFFFu;
+        const bool anyhit_now = ANYHIT && shadow_cast;
+        // no triangle/node beyond `lim` can matter: the light for a deciding shadow ray, else the
+        // nearest hit so far (other objects, then this mesh)
+        float lim = anyhit_now ? light_dist : best;
 
-        // one triangle against the lanes in `lanes` (wave-uniform T: SGPR operands)
-        auto tri_test = [&](const CADDR DTri &T, uint32_t tri_index, bool lanes) {
-          bool c = lanes;
+        // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
+        auto tri_test = [&](const CADDR DTri &T, uint32_t tri_index, mask_t lanes_m) {
+          mask_t c_m = lanes_m;
           if (STATS) st[2]++;
+          const float dx = T.px - ro.x, dy = T.py - ro.y, dz = T.pz - ro.z;
           if (PREFILTER) {
             // Conservative reject test.  Same quantities as the exact test
             // (alpha = det[a b c], A1 = det[d b c], A2 = det[a d c]) evaluated with FMAs
             // as triple products; every comparison carries a slack E that bounds both this
             // evaluation's and the reference's rounding, and a
             // NaN anywhere makes the lane a candidate.
-            const float dx = T.px - ro.x, dy = T.py - ro.y, dz = T.pz - ro.z;
             const float alpha = __builtin_fmaf(rd.x, T.nx, __builtin_fmaf(rd.y, T.ny, rd.z * T.nz));
             const float qx = __builtin_fmaf(dy, rd.z, -(dz * rd.y));
             const float qy = __builtin_fmaf(dz, rd.x, -(dx * rd.z));
@@ -282,31 +320,64 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             const float absa = fabsf(alpha);
             const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
             const float E = fmaxf(dmax * T.ke, T.ke2) * cmax;  // kappa * max(dmax,emax) * emax * cmax
-            const bool rej = (sA1 < -E) | (sA2 < -E) | ((sA1 + sA2) > (absa + E));
-            c = lanes && (!rej || (absa <= E));
+            const mask_t rej = FCMP(sA1, -E, FC_OLT) | FCMP(sA2, -E, FC_OLT) | FCMP(sA1 + sA2, absa + E, FC_OGT);
+            c_m = lanes_m & (~rej | FCMP(absa, E, FC_OLE));
           }
-          if (BALLOT(c) != 0ull) {
-            if (STATS) st[3]++;
-            if (c) {
-              // ---- triangle::intersect, default_schema.hpp:57-78, reference op order ----
-              const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
-              const V3 d = mk(T.px - ro.x, T.py - ro.y, T.pz - ro.z);
-              const float alpha = det3(a, b, rd);
-              const float beta = det3(d, b, rd) / alpha;
-              const float gamma = det3(a, d, rd) / alpha;
-              const float t0 = det3(a, b, d) / alpha;
-              if (beta >= 0 && gamma >= 0 && beta + gamma <= 1 && __builtin_isfinite(t0) && min_t <= t0) {
+          if (c_m == 0ull) return;
+          if (STATS) st[3]++;
+          bool retire = false;  // any-hit: this lane found its occluder
+          if (INVB(c_m)) {
+            // ---- triangle::intersect, default_schema.hpp:57-78: the four determinants in the
+            //      reference's operation order ----
+            const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
+            const V3 d = mk(dx, dy, dz);
+            const float alpha = det3(a, b, rd);
+            const float A1 = det3(d, b, rd), A2 = det3(a, d, rd), A0 = det3(a, b, d);
+            // The three IEEE divisions (beta, gamma, t0) decide five comparisons and deliver t0.
+            // 1-ulp-reciprocal quotients are within 2^-21 relative of the exact ones, so with a
+            // 2^-18 margin (and an absolute floor for zero/denormal quotients) most lanes are
+            // decided without dividing; t0 itself is divided only where its value can matter.
+            const float r = __builtin_amdgcn_rcpf(alpha);
+            const float bq = A1 * r, gq = A2 * r, tq = A0 * r, sq = bq + gq;
+            const float eb = fabsf(bq) * 0x1p-18f + 1e-30f, eg = fabsf(gq) * 0x1p-18f + 1e-30f;
+            const float es = (fabsf(bq) + fabsf(gq) + 1.0f) * 0x1p-16f;
+            const float et = fabsf(tq) * 0x1p-18f + 1e-30f;
+            const bool def_rej = (bq < -eb) | (gq < -eg) | (sq > 1.0f + es) | (tq < min_t - et);
+            const bool def_acc = (bq > eb) & (gq > eg) & (sq < 1.0f - es) & (tq > min_t + et) & (fabsf(tq) < 1e37f);
+            bool acc = def_acc;
+            float t0 = tq;
+            bool exact_t = false;
+            if (!(def_rej | def_acc)) {
+              // borderline (or NaN/inf): the reference's own arithmetic
+              const float beta = A1 / alpha, gamma = A2 / alpha;
+              t0 = A0 / alpha;
+              exact_t = true;
+              acc = beta >= 0 && gamma >= 0 && beta + gamma <= 1 && __builtin_isfinite(t0) && min_t <= t0;
+            }
+            if (acc) {
+              if (anyhit_now) {
+                // A deciding shadow ray only asks whether some valid t lies in (min_t, light_dist).
+                // tq is within et of the exact t0 and already > min_t + et, so divide only when tq is
+                // within et of the light distance.
+                if (!exact_t && !(tq + et < light_dist) && !(tq - et >= light_dist)) t0 = A0 / alpha;
+                if (t0 > min_t && t0 < light_dist) {
+                  best = t0; bobj = (int)i;   // any value < light_dist: the handler only compares
+                  retire = true;
+                }
+              } else {
+                // the exact value of t0 matters only if it can beat or tie the nearest hit so far
+                if (!exact_t && !(tq - et > lim)) { t0 = A0 / alpha; exact_t = true; }
                 const uint32_t orig = T.orig;
-                if (t0 < mt || (t0 == mt && orig < morig)) { mt = t0; mk_ = (int)tri_index; morig = orig; }
-                if (ANYHIT) {
-                  // an occluder in (min_t, light_dist): this lane's shadow loop is decided
-                  if (shadow_cast && t0 > min_t && t0 < light_dist) {
-                    bb = false; live = false;
-                    best = t0; bobj = (int)i;
-                  }
+                if (exact_t && (t0 < mt || (t0 == mt && orig < morig))) {
+                  mt = t0; mk_ = (int)tri_index; morig = orig;
+                  lim = fminf(lim, mt);
                 }
               }
             }
+          }
+          if (ANYHIT) {
+            const mask_t rm = BALLOT(retire);
+            bb_m &= ~rm;
           }
         };
 
@@ -319,29 +390,28 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           const float gy = fmaxf(fabsf(O.f[1] - ro.y), fabsf(O.f[4] - ro.y));
           const float gz = fmaxf(fabsf(O.f[2] - ro.z), fabsf(O.f[5] - ro.z));
           const float slack = (fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f) *
-                              fmaxf(fmaxf(fabsf(rinv.x), fabsf(rinv.y)), fabsf(rinv.z));
-          const V3 roi = mk(ro.x * rinv.x, ro.y * rinv.y, ro.z * rinv.z);  // box test as fma(b, 1/d, -o/d)
+                              fmaxf(fmaxf(fabsf(ria.x), fabsf(ria.y)), fabsf(ria.z));
+          const float min_ts = min_t - slack;
           const CADDR DNode *nodes = A.nodes + O.node_begin;
           const uint32_t n_nodes = O.node_count;
           uint32_t ni = 0;
           while (ni < n_nodes) {
             const CADDR DNode &N = nodes[ni];
             if (STATS) st[1]++;
-            const float t1x = __builtin_fmaf(N.mnx, rinv.x, -roi.x), t2x = __builtin_fmaf(N.mxx, rinv.x, -roi.x);
-            const float t1y = __builtin_fmaf(N.mny, rinv.y, -roi.y), t2y = __builtin_fmaf(N.mxy, rinv.y, -roi.y);
-            const float t1z = __builtin_fmaf(N.mnz, rinv.z, -roi.z), t2z = __builtin_fmaf(N.mxz, rinv.z, -roi.z);
-            const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+            const float t1x = __builtin_fmaf(N.mnx, ria.x, -roi.x), t2x = __builtin_fmaf(N.mxx, ria.x, -roi.x);
+            const float t1y = __builtin_fmaf(N.mny, ria.y, -roi.y), t2y = __builtin_fmaf(N.mxy, ria.y, -roi.y);
+            const float t1z = __builtin_fmaf(N.mnz, ria.z, -roi.z), t2z = __builtin_fmaf(N.mxz, ria.z, -roi.z);
+            const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z)) - slack;
             const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
             // reject only on a definite miss (NaN compares false -> the node is entered)
-            const float far_lim = (ANYHIT && shadow_cast) ? light_dist : fminf(best, mt);
-            const bool miss = ((lo - slack) > hi) | ((hi + slack) < min_t) | ((lo - slack) > far_lim);
-            const bool hnode = bb && !miss;
-            if (BALLOT(hnode) != 0ull) {
+            const mask_t miss = FCMP(lo, hi, FC_OGT) | FCMP(hi, min_ts, FC_OLT) | FCMP(lo, lim, FC_OGT);
+            const mask_t h_m = bb_m & ~miss;
+            if (h_m != 0ull) {
               const uint32_t cnt_l = N.count, first = N.first;
-              for (uint32_t k = 0; k < cnt_l; ++k) tri_test(A.tris[first + k], first + k, hnode);
+              for (uint32_t k = 0; k < cnt_l; ++k) tri_test(A.tris[first + k], first + k, h_m & bb_m);
               ni += 1;
               if (ANYHIT) {
-                if (BALLOT(bb) == 0ull) break;
+                if (bb_m == 0ull) break;
               }
             } else {
               ni = N.skip;
@@ -349,12 +419,13 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           }
         } else {
           for (uint32_t k = 0; k < cnt; ++k) {
-            tri_test(A.tris[beg + k], beg + k, bb);  // wave-uniform: one s_load_dwordx16
+            tri_test(A.tris[beg + k], beg + k, bb_m);  // wave-uniform: one s_load_dwordx16
             if (ANYHIT) {
-              if (BALLOT(bb) == 0ull) break;
+              if (bb_m == 0ull) break;
             }
           }
         }
+        if (ANYHIT) live = live && !INVB(bb0_m & ~bb_m);  // lanes retired inside the mesh
         ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
         cand = mt;
         ctri = mk_;
