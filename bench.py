@@ -125,7 +125,7 @@ def main():
             ctypes.memmove(ctypes.byref(c), ctypes.byref(cam0), ctypes.sizeof(ca.Camera))
             cams.append(c)
         ds.set_cameras(cams)
-    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    counters = torch.zeros(16, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
 
     step_no = [0]

@@ -106,6 +106,7 @@ struct ctr_scene {
   // cached device outputs for the host-buffer form
   float *d_depth = nullptr, *d_color = nullptr, *d_normal = nullptr;
   unsigned long long *d_counters = nullptr;
+  unsigned long long *d_shards = nullptr;  // CTR_SHARDS x CTR_SHARD_WORDS, zero between launches
   size_t out_px = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mtx;
@@ -177,6 +178,7 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.has_mesh = s->has_mesh ? 1u : 0u;
   L.need_cold_frames = s->need_cold ? 1u : 0u;
   L.cams = s->d_cams;
+  L.shards = s->d_shards;
   L.w = s->cam.w;
   L.h = s->cam.h;
   L.first_frame = 0;
@@ -358,6 +360,8 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
       (er = upload((void **)&s->d_mats, mats.data(), mats.size() * sizeof(DMat))) != hipSuccess ||
       (er = upload((void **)&s->d_cams, &s->cam, sizeof(DCam))) != hipSuccess ||
       (er = hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
+      (er = hipMalloc((void **)&s->d_shards, (size_t)CTR_SHARDS * CTR_SHARD_WORDS * sizeof(unsigned long long))) != hipSuccess ||
+      (er = hipMemset(s->d_shards, 0, (size_t)CTR_SHARDS * CTR_SHARD_WORDS * sizeof(unsigned long long))) != hipSuccess ||
       (er = hipEventCreate(&s->ev0)) != hipSuccess || (er = hipEventCreate(&s->ev1)) != hipSuccess) {
     ctr_scene_destroy(s);
     return hip_fail(er, "scene upload");
@@ -394,7 +398,7 @@ void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : {(void *)s->d_objs, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
-                  (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters})
+                  (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters, (void *)s->d_shards})
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);

@@ -114,12 +114,16 @@ struct RenderLaunch {
   float *depth;
   float *color;
   float *normal;
+  unsigned long long *shards;    // scene-owned CTR_SHARDS x CTR_SHARD_WORDS scratch the kernel adds into
   unsigned long long *counters;  // [0] ray_count, [1] max-depth bits, [2] AABB-hit triangle count (KV_COUNT), [4..9] KV_STATS
   uint32_t variant;
 };
 
 // host-callable launcher implemented in render_kernel.hip; returns a hipError_t as int
 int ctr_launch_render(const RenderLaunch &L, void *stream);
+// counters are accumulated in CTR_SHARDS 128-byte shards (see render_kernel.hip) and folded afterwards
+#define CTR_SHARDS 1024
+#define CTR_SHARD_WORDS 16
 // maximum `bounces` the kernel supports (explicit per-lane stack depth - 1)
 #define CTR_MAX_BOUNCES 15
 

@@ -165,9 +165,11 @@ int ctr_render(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
 /* Device-buffer form: outputs are DEVICE pointers on the scene's device (e.g.
  * torch tensors' data_ptr()), the launch is asynchronous on `hip_stream`
  * (a hipStream_t, NULL = default stream).  No allocation, no sync inside:
- * graph-capturable.  d_counters: optional device pointer to 2×uint64
- * {ray_count, max_depth_bits}; the kernel ACCUMULATES into it (atomic add /
- * atomic max), so zero it before the first launch of a frame. */
+ * graph-capturable.  d_counters: optional device pointer to 16×uint64
+ * ([0] ray_count, [1] max_depth bits, rest reserved); the call ACCUMULATES into it
+ * (add / max), so zero it before the first launch of a frame.  A scene handle keeps one
+ * internal reduction scratch: launches of the SAME handle that use counters must be on one
+ * stream at a time. */
 int ctr_render_device(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
                       void *d_depth, void *d_color3, void *d_normal3,
                       void *d_counters, void *hip_stream);

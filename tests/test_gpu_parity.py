@@ -155,7 +155,7 @@ def test_device_buffer_form_with_torch(gpu):
     depth = torch.empty(54 * 96, dtype=torch.float32, device=dev)
     color = torch.empty(54 * 96 * 3, dtype=torch.float32, device=dev)
     normal = torch.empty(54 * 96 * 3, dtype=torch.float32, device=dev)
-    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    counters = torch.zeros(16, dtype=torch.int64, device=dev)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         ds.render_device(depth.data_ptr(), color.data_ptr(), normal.data_ptr(), counters.data_ptr(),
