@@ -440,6 +440,8 @@ int ctr_render_device_batch(ctr_scene *s, float fudge, int bounces, const ctr_ro
   if (!d_depth || !d_color3 || !d_normal3) return fail(CTR_E_INVALID, "null output buffer");
   if (n_frames == 0 || first_frame >= s->n_cams || n_frames > s->n_cams - first_frame)
     return fail(CTR_E_INVALID, "frame range exceeds the cameras set with ctr_scene_set_cameras");
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur != s->device) HIP_TRY(hipSetDevice(s->device));
   RenderLaunch L{};
   fill_launch(s, L);
   if ((st = make_rows(s, rows, L.rows))) return st;

@@ -43,6 +43,7 @@
 
 #define CADDR __attribute__((address_space(4)))
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
+#define PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))  /* opaque to LICM / speculation */
 #define INVB(m) __builtin_amdgcn_inverse_ballot_w64(m)   /* wave-uniform lane mask -> per-lane predicate */
 #define FCMP(a, b, pred) __builtin_amdgcn_fcmpf((a), (b), (pred))  /* v_cmp straight into a lane mask */
 enum { FC_OGT = 2, FC_OGE = 3, FC_OLT = 4, FC_OLE = 5 };          /* LLVM FCmp predicate numbers */
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
 
   const uint32_t w = A.w, h = A.h;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * WAVES_PER_WG) + (threadIdx.x >> 6);
+  const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
+  const uint32_t wave = (blockIdx.x * WAVES_PER_WG) + wave_in_wg;
   const uint32_t tiles_x = (w + TW - 1) / TW;
   const uint32_t tiles_y = (A.rows.n_rows + TH - 1) / TH;
   const uint32_t tiles_frame = tiles_x * tiles_y;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   float min_t = A.fudge;
   int sp = 0;               // stack depth; bounces left for the current activation = bounces - sp
   extern __shared__ float lds_stack[];
-  float *const stk = lds_stack + (size_t)(threadIdx.x >> 6) * A.frames * A.nf * 64 + lane;
+  float *const stk = lds_stack + (size_t)wave_in_wg * A.frames * A.nf * 64 + lane;
 #define STK(frame, field) stk[((frame) * A.nf + (field)) * 64]
   V3 in_d = rd;             // direction of the radiance ray being shaded ("incoming"); its start is `ro` until the hit
   V3 hit = mk(0, 0, 0), nn = mk(0, 0, 0), pos = mk(0, 0, 0);
@@ -266,7 +268,9 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           bb_m = live_m & def_hit;
           if (border != 0ull) {
             if (!have_rinv) {  // wave-uniform: the exact reciprocals are computed at most once per cast
-              rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);  // default_schema.hpp:103
+              float ox = rd.x, oy = rd.y, oz = rd.z;
+              PIN3(ox, oy, oz);  // keeps the three IEEE divisions in this rarely-taken branch (no hoisting)
+              rinv = mk(1.0f / ox, 1.0f / oy, 1.0f / oz);  // default_schema.hpp:103
               have_rinv = true;
             }
             float tmin = 0.0f, tmax = INFINITY;
@@ -446,7 +450,9 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         }
       } else if (type == CTR_OBJ_SPHERE) {
         // ---- sphere::intersect, default_schema.hpp:226-251 ----
-        const V3 d = vnormalized(rd), c = mk(O.f[0], O.f[1], O.f[2]);
+        float sx_ = rd.x, sy_ = rd.y, sz_ = rd.z;
+        PIN3(sx_, sy_, sz_);  // do not speculate the normalisation into scenes without spheres
+        const V3 d = vnormalized(mk(sx_, sy_, sz_)), c = mk(O.f[0], O.f[1], O.f[2]);
         const float R = O.f[3];
         const V3 ec = vsub(ro, c);
         const float dec = -vdot(d, ec);
