@@ -27,28 +27,33 @@ struct Box {
 struct Builder {
   const std::vector<BvhInput> &prims;
   uint32_t leaf_size;
+  bool median_only;  // depth-bounded fallback
   std::vector<DNode> &nodes;
   std::vector<uint32_t> &order;
+  int max_depth = 0;
 
   static constexpr int NBINS = 16;
 
-  uint32_t build(uint32_t begin, uint32_t end) {
-    const uint32_t me = (uint32_t)nodes.size();
-    nodes.emplace_back();
-    Box b, cb;
-    for (uint32_t i = begin; i < end; i++) {
-      const BvhInput &p = prims[order[i]];
-      b.grow(p.mn, p.mx);
-      cb.grow_pt(p.c);
-    }
-    DNode nd;
-    memset(&nd, 0, sizeof(nd));
-    nd.mnx = b.mn[0]; nd.mny = b.mn[1]; nd.mnz = b.mn[2];
-    nd.mxx = b.mx[0]; nd.mxy = b.mx[1]; nd.mxz = b.mx[2];
+  Box bounds(uint32_t begin, uint32_t end) const {
+    Box b;
+    for (uint32_t i = begin; i < end; i++) b.grow(prims[order[i]].mn, prims[order[i]].mx);
+    return b;
+  }
+
+  // returns the child descriptor of the subtree over [begin, end)
+  uint32_t build(uint32_t begin, uint32_t end, int depth) {
+    max_depth = std::max(max_depth, depth);
     const uint32_t n = end - begin;
-    bool leaf = n <= leaf_size;
+    if (n <= leaf_size) return BVH_LEAF_FLAG | (n << 24) | begin;
+    Box cb;
+    for (uint32_t i = begin; i < end; i++) cb.grow_pt(prims[order[i]].c);
     uint32_t mid = begin;
-    if (!leaf) {
+    int axis = 0;
+    {
+      float e0 = cb.mx[0] - cb.mn[0], e1 = cb.mx[1] - cb.mn[1], e2 = cb.mx[2] - cb.mn[2];
+      axis = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2);
+    }
+    if (!median_only) {
       // binned SAH over the three axes
       float best_cost = std::numeric_limits<float>::infinity();
       int best_axis = -1, best_bin = -1;
@@ -86,6 +91,7 @@ struct Builder {
       }
       if (best_axis >= 0) {
         const int a = best_axis;
+        axis = a;
         const float lo = cb.mn[a], scale = (float)NBINS / (cb.mx[a] - cb.mn[a]);
         auto it = std::partition(order.begin() + begin, order.begin() + end, [&](uint32_t id) {
           int bi = std::min(NBINS - 1, std::max(0, (int)((prims[id].c[a] - lo) * scale)));
@@ -93,20 +99,25 @@ struct Builder {
         });
         mid = (uint32_t)(it - order.begin());
       }
-      if (mid == begin || mid == end) mid = begin + n / 2;  // coincident centroids: split by count
     }
-    if (leaf) {
-      nd.first = begin;
-      nd.count = n;
-      nd.skip = me + 1;
-      nodes[me] = nd;
-      return me;
+    if (mid == begin || mid == end) {
+      // coincident centroids / SAH failed / median mode: split by count along the widest axis
+      mid = begin + n / 2;
+      std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end,
+                       [&](uint32_t x, uint32_t y) { return prims[x].c[axis] < prims[y].c[axis]; });
     }
-    nd.count = 0;
+    const uint32_t me = (uint32_t)nodes.size();
+    nodes.emplace_back();
+    const uint32_t l = build(begin, mid, depth + 1);
+    const uint32_t r = build(mid, end, depth + 1);
+    DNode nd;
+    memset(&nd, 0, sizeof(nd));
+    Box lb = bounds(begin, mid), rb = bounds(mid, end);
+    for (int a = 0; a < 3; a++) { nd.lmn[a] = lb.mn[a]; nd.lmx[a] = lb.mx[a]; nd.rmn[a] = rb.mn[a]; nd.rmx[a] = rb.mx[a]; }
+    nd.left = l;
+    nd.right = r;
+    nd.axis = (uint32_t)axis;
     nodes[me] = nd;
-    build(begin, mid);
-    build(mid, end);
-    nodes[me].skip = (uint32_t)nodes.size();
     return me;
   }
 };
@@ -114,15 +125,27 @@ struct Builder {
 }  // namespace
 
 void bvh_build(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vector<DNode> &nodes,
-               std::vector<uint32_t> &order) {
+               std::vector<uint32_t> &order, uint32_t &root) {
   nodes.clear();
   order.resize(prims.size());
-  for (uint32_t i = 0; i < prims.size(); i++) order[i] = i;
+  root = BVH_LEAF_FLAG;  // empty leaf
   if (prims.empty()) return;
   if (leaf_size < 1) leaf_size = 1;
-  Builder b{prims, leaf_size, nodes, order};
-  b.build(0, (uint32_t)prims.size());
+  if (leaf_size > BVH_MAX_LEAF) leaf_size = BVH_MAX_LEAF;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    nodes.clear();
+    for (uint32_t i = 0; i < prims.size(); i++) order[i] = i;
+    Builder b{prims, leaf_size, attempt == 1, nodes, order};
+    root = b.build(0, (uint32_t)prims.size(), 0);
+    if (b.max_depth <= BVH_MAX_DEPTH) break;  // else rebuild with balanced (median) splits: depth = log2(n)
+  }
   // keep file order inside every leaf (cheap determinism; ties are broken by original index anyway)
-  for (const DNode &n : nodes)
-    if (n.count) std::sort(order.begin() + n.first, order.begin() + n.first + n.count);
+  auto sort_leaf = [&](uint32_t d) {
+    if (d & BVH_LEAF_FLAG) {
+      uint32_t first = d & 0xFFFFFFu, cnt = (d >> 24) & 0x7Fu;
+      std::sort(order.begin() + first, order.begin() + first + cnt);
+    }
+  };
+  sort_leaf(root);
+  for (const DNode &n : nodes) { sort_leaf(n.left); sort_leaf(n.right); }
 }

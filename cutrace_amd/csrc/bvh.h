@@ -7,23 +7,30 @@
 // tested as long as ties are broken by the original index.  So the kernel is free to
 // visit triangles through a hierarchy and skip whole subtrees no lane's ray can touch.
 //
-// Layout: nodes in depth-first pre-order with a skip link (stackless "threaded" BVH),
-// because the whole WAVE walks the tree together (a subtree is entered when ANY lane
-// hits its box): next = hit ? i+1 : skip[i].  One node = one 64-byte line = one
-// s_load_dwordx16.  Leaves own a contiguous range of the (reordered) triangle array.
+// Layout ("children in parent"): only INNER nodes are stored.  One node = one 64-byte
+// line = one s_load_dwordx16 and holds the boxes of BOTH children plus what each child is
+// (another inner node, or a leaf = a contiguous range of the reordered triangle array).
+// A child whose box no lane touches is therefore never loaded at all, and leaves cost no
+// node load.  The whole WAVE walks the tree together with a small wave-uniform stack.
 #ifndef CUTRACE_AMD_BVH_H
 #define CUTRACE_AMD_BVH_H
 
 #include <stdint.h>
 #include <vector>
 
+// child descriptor: bit 31 set -> leaf: bits 24..30 = triangle count (1..127), bits 0..23 = first
+// triangle (relative to the mesh's first triangle); bit 31 clear -> index of the inner child node
+// (relative to the mesh's first node)
+#define BVH_LEAF_FLAG 0x80000000u
+#define BVH_MAX_LEAF 127u
+#define BVH_MAX_DEPTH 60  // the kernel keeps its stack in the 64 lanes of one VGPR
+
 struct DNode {
-  float mnx, mny, mnz;   // box min
-  float mxx, mxy, mxz;   // box max
-  uint32_t skip;         // node index (relative to the mesh's first node) to continue with when culled
-  uint32_t first;        // leaf: first triangle (absolute index into the device triangle array)
-  uint32_t count;        // leaf: number of triangles; inner node: 0
-  uint32_t pad[7];
+  float lmn[3], lmx[3];  // left child's box
+  float rmn[3], rmx[3];  // right child's box
+  uint32_t left, right;  // child descriptors
+  uint32_t axis;         // split axis (0,1,2): the child on the ray's near side is visited first
+  uint32_t pad;
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
@@ -32,10 +39,10 @@ struct BvhInput {
   float mn[3], mx[3], c[3];
 };
 
-// Builds a binned-SAH BVH over `n` primitives.  Returns nodes (pre-order, skip links relative
-// to node 0; leaf.first relative to 0 in the PERMUTED order) and `order` = permutation such that
-// permuted[i] = original[order[i]].
+// Builds a binned-SAH BVH over `n` primitives.  `root` receives the root's child descriptor (a
+// leaf descriptor when everything fits one leaf, in which case `nodes` is empty); `order` is the
+// permutation such that permuted[i] = original[order[i]].
 void bvh_build(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vector<DNode> &nodes,
-               std::vector<uint32_t> &order);
+               std::vector<uint32_t> &order, uint32_t &root);
 
 #endif

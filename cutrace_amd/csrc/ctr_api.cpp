@@ -286,17 +286,17 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
             b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
           }
         }
+        if (n > 0xFFFFFFu) return fail(CTR_E_INVALID, "object #" + std::to_string(i) + ": mesh has more than 2^24 triangles");
         std::vector<DNode> mnodes;
         std::vector<uint32_t> order;
-        bvh_build(prims, BVH_LEAF, mnodes, order);
+        uint32_t root = 0;
+        bvh_build(prims, BVH_LEAF, mnodes, order, root);
         O.tri_begin = (uint32_t)tris.size();
         O.tri_count = n;
         O.node_begin = (uint32_t)nodes.size();
         O.node_count = (uint32_t)mnodes.size();
-        for (DNode &nd : mnodes) {
-          if (nd.count) nd.first += O.tri_begin;  // absolute triangle index
-          nodes.push_back(nd);                    // skip stays relative to the mesh's first node
-        }
+        O.bvh_root = root;  // child descriptors stay relative to the mesh's first node / first triangle
+        nodes.insert(nodes.end(), mnodes.begin(), mnodes.end());
         tris.resize(tris.size() + n);
         gn.resize(4 * tris.size());
         for (uint32_t k = 0; k < n; k++) {
@@ -519,6 +519,9 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
     fprintf(stderr, "cutrace_amd stats: wave_casts=%llu nodes=%llu tri_prefilter=%llu tri_exact=%llu mesh_entries=%llu "
                     "active_lanes=%llu kernel_ms=%.3f\n", cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], cnt[9], ms);
   if (aabb_tris) *aabb_tris = cnt[2];
+  if (cnt[13])  // CTR_TIMING diagnostic build
+    fprintf(stderr, "cutrace_amd timing (wave-cycles): object_loop=%llu mesh=%llu continuation=%llu wave_total=%llu "
+                    "kernel_ms=%.3f\n", cnt[10], cnt[11], cnt[12], cnt[13], ms);
   auto t1 = std::chrono::high_resolution_clock::now();
   if (stats) {
     stats->kernel_ms = ms;

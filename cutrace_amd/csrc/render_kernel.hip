@@ -59,6 +59,12 @@ namespace {
 #ifndef CTR_WAVES_PER_WG
 #define CTR_WAVES_PER_WG 1
 #endif
+#ifndef CTR_WHOLE_OBJ
+#define CTR_WHOLE_OBJ 0
+#endif
+#ifndef CTR_PREFETCH
+#define CTR_PREFETCH 0
+#endif
 #ifndef CTR_TILE_STRIDE
 #define CTR_TILE_STRIDE 1
 #endif
@@ -104,6 +110,18 @@ __device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a
 // (every push decrements it): bl = bounces - depth.
 enum { F_R = 0, F_G, F_B, F_REFL, F_TRANSL, F_STAGE, F_PX, F_PY, F_PZ, F_DX, F_DY, F_DZ };
 
+// copy one 64-byte record out of the constant address space (16 dwords -> SGPRs when uniform)
+template <class T>
+__device__ __forceinline__ T ldc(const CADDR T *p) {
+  static_assert(sizeof(T) == 64, "64-byte records only");
+  T r;
+  const CADDR uint32_t *src = (const CADDR uint32_t *)p;
+  uint32_t *dst = (uint32_t *)&r;
+#pragma unroll
+  for (int q = 0; q < 16; q++) dst[q] = src[q];
+  return r;
+}
+
 struct KArgs {
   const CADDR DObj *objs;
   const CADDR DTri *tris;
@@ -142,6 +160,17 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+#ifdef CTR_TIMING
+  // diagnostic build only: shader-clock stamps per wave -> shards[10..13] = {object loop, mesh branch,
+  // continuation, whole wave}
+  unsigned long long tm[4] = {0, 0, 0, 0};
+  const unsigned long long tm_start = __builtin_readcyclecounter();
+#define TSTAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#define TACC(i, a, b) tm[i] += (b) - (a)
+#else
+#define TSTAMP(v)
+#define TACC(i, a, b)
+#endif
 
   const uint32_t w = A.w, h = A.h;
   const uint32_t lane = threadIdx.x & 63u;
@@ -236,8 +265,22 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       cmax = fmaxf(fmaxf(fabsf(rd.x), fabsf(rd.y)), fabsf(rd.z));
     }
 
+    TSTAMP(t_loop0);
+#if CTR_PREFETCH
+    // software pipeline of the wave-uniform record loads: object i+1 is requested before object i is
+    // processed (scalar loads return out of order, so the wait for record i must come BEFORE the next
+    // request is issued — copying it into `O` does that)
+    DObj o_next = ldc(&A.objs[0]);  // the array always holds at least one (possibly unused) record
+#endif
     for (uint32_t i = 0; i < A.n_obj; ++i) {
+#if CTR_PREFETCH
+      const DObj O = o_next;
+      if (i + 1 < A.n_obj) o_next = ldc(&A.objs[i + 1]);
+#elif CTR_WHOLE_OBJ
+      const DObj O = ldc(&A.objs[i]);  // one 64-byte request instead of type-then-payload (two latencies)
+#else
       const CADDR DObj &O = A.objs[i];
+#endif
       const uint32_t type = O.type;
       bool ok = false;
       float cand = INFINITY;
@@ -246,6 +289,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         // Everything in this branch works on 64-bit lane masks (v_cmp results kept in SGPRs and
         // combined on the scalar unit) instead of per-lane booleans.
         typedef unsigned long long mask_t;
+        TSTAMP(t_mesh0);
         const mask_t live_m = BALLOT(live);
         // ---- mesh::bound_intersects, default_schema.hpp:99-114 ----
         // The reference's slab test needs three IEEE divisions (1/dir) per ray.  With 1-ulp
@@ -286,7 +330,11 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             bb_m |= border & FCMP(tmin, tmax, FC_OLE);
           }
         }
-        if (bb_m == 0ull) continue;  // no lane of this wave needs the mesh
+        if (bb_m == 0ull) {  // no lane of this wave needs the mesh
+          TSTAMP(t_mesh_skip);
+          TACC(1, t_mesh0, t_mesh_skip);
+          continue;
+        }
         const mask_t bb0_m = bb_m;
         const uint32_t beg = O.tri_begin, cnt = O.tri_count;
         if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
@@ -302,7 +350,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         float lim = anyhit_now ? light_dist : best;
 
         // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
-        auto tri_test = [&](const CADDR DTri &T, uint32_t tri_index, mask_t lanes_m) {
+        auto tri_test = [&](const auto &T, uint32_t tri_index, mask_t lanes_m) {
           mask_t c_m = lanes_m;
           if (STATS) st[2]++;
           const float dx = T.px - ro.x, dy = T.py - ro.y, dz = T.pz - ro.z;
@@ -386,10 +434,13 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         };
 
         if (BVH) {
-          // Stackless walk of the mesh's pre-order BVH, the whole wave together: a subtree is
-          // entered when ANY lane's ray touches its box.  The box test is conservative: boxes are
-          // widened by m = 2^-15 x (largest |coordinate difference| between the ray origin and the
-          // mesh), applied in t-space as a slack of 2*m*max|1/dir|.
+          // Walk of the mesh's BVH by the whole wave together (bvh.h): an inner node holds BOTH
+          // children's boxes, so a child no lane touches is never loaded and leaves cost no node
+          // load.  Pending inner children wait on a wave-uniform stack kept in the lanes of ONE
+          // VGPR (v_writelane / v_readlane); the child on the near side of the split axis goes
+          // first.  The box test is conservative: boxes are widened by m = 2^-15 x (largest
+          // |coordinate difference| between the ray origin and the mesh), applied in t-space as a
+          // slack of 2*m*max|1/dir|; a NaN enters the box.
           const float gx = fmaxf(fabsf(O.f[0] - ro.x), fabsf(O.f[3] - ro.x));
           const float gy = fmaxf(fabsf(O.f[1] - ro.y), fabsf(O.f[4] - ro.y));
           const float gz = fmaxf(fabsf(O.f[2] - ro.z), fabsf(O.f[5] - ro.z));
@@ -397,28 +448,66 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
                               fmaxf(fmaxf(fabsf(ria.x), fabsf(ria.y)), fabsf(ria.z));
           const float min_ts = min_t - slack;
           const CADDR DNode *nodes = A.nodes + O.node_begin;
-          const uint32_t n_nodes = O.node_count;
-          uint32_t ni = 0;
-          while (ni < n_nodes) {
-            const CADDR DNode &N = nodes[ni];
-            if (STATS) st[1]++;
-            const float t1x = __builtin_fmaf(N.mnx, ria.x, -roi.x), t2x = __builtin_fmaf(N.mxx, ria.x, -roi.x);
-            const float t1y = __builtin_fmaf(N.mny, ria.y, -roi.y), t2y = __builtin_fmaf(N.mxy, ria.y, -roi.y);
-            const float t1z = __builtin_fmaf(N.mnz, ria.z, -roi.z), t2z = __builtin_fmaf(N.mxz, ria.z, -roi.z);
+          // direction signs of the first lane that needs the mesh decide the visiting order (speed only)
+          const uint32_t lead = (uint32_t)__builtin_ctzll(bb_m);
+          const uint32_t neg_bits = (__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31) |
+                                    ((__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31) << 1) |
+                                    ((__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31) << 2);
+          auto box_hits = [&](const auto &mn, const auto &mx) -> mask_t {
+            const float t1x = __builtin_fmaf(mn[0], ria.x, -roi.x), t2x = __builtin_fmaf(mx[0], ria.x, -roi.x);
+            const float t1y = __builtin_fmaf(mn[1], ria.y, -roi.y), t2y = __builtin_fmaf(mx[1], ria.y, -roi.y);
+            const float t1z = __builtin_fmaf(mn[2], ria.z, -roi.z), t2z = __builtin_fmaf(mx[2], ria.z, -roi.z);
             const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z)) - slack;
             const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-            // reject only on a definite miss (NaN compares false -> the node is entered)
+            // reject only on a definite miss (NaN compares false -> the box is entered)
             const mask_t miss = FCMP(lo, hi, FC_OGT) | FCMP(hi, min_ts, FC_OLT) | FCMP(lo, lim, FC_OGT);
-            const mask_t h_m = bb_m & ~miss;
-            if (h_m != 0ull) {
-              const uint32_t cnt_l = N.count, first = N.first;
-              for (uint32_t k = 0; k < cnt_l; ++k) tri_test(A.tris[first + k], first + k, h_m & bb_m);
-              ni += 1;
+            return bb_m & ~miss;
+          };
+          auto leaf = [&](uint32_t desc, mask_t lanes) {
+            const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
+            for (uint32_t k = 0; k < n_l; ++k) tri_test(A.tris[first + k], first + k, lanes & bb_m);
+          };
+          uint32_t cur = O.bvh_root;
+          if (cur & BVH_LEAF_FLAG) {
+            leaf(cur, bb_m);  // the whole mesh fits one leaf
+          } else {
+            uint32_t stack_v = 0;  // lane k of this VGPR = stack slot k (depth <= BVH_MAX_DEPTH < 64)
+            uint32_t sp = 0;
+            for (;;) {
+              const CADDR DNode &N = nodes[cur];
+              if (STATS) st[1]++;
+              // near child first
+              const bool swap = ((neg_bits >> N.axis) & 1u) != 0u;
+              const mask_t hl = box_hits(N.lmn, N.lmx), hr = box_hits(N.rmn, N.rmx);
+              const uint32_t d0 = swap ? N.right : N.left, d1 = swap ? N.left : N.right;
+              const mask_t h0 = swap ? hr : hl, h1 = swap ? hl : hr;
+              uint32_t next = 0xFFFFFFFFu;
+              if (h0 != 0ull) {
+                if (d0 & BVH_LEAF_FLAG) leaf(d0, h0);
+                else next = d0;
+              }
+              if (h1 != 0ull && !(ANYHIT && bb_m == 0ull)) {
+                if (d1 & BVH_LEAF_FLAG) {
+                  // d0's leaf may have pulled `lim` in: lanes whose far box now lies beyond it drop out
+                  leaf(d1, h1);
+                } else if (next == 0xFFFFFFFFu) {
+                  next = d1;
+                } else {
+                  // v_writelane_b32: value and lane select are both wave-uniform; gfx9 allows one SGPR
+                  // operand per VALU instruction, so the lane select travels in M0
+                  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stack_v) : "s"(d1), "s"(sp) : "m0");
+                  sp++;
+                }
+              }
               if (ANYHIT) {
                 if (bb_m == 0ull) break;
               }
-            } else {
-              ni = N.skip;
+              if (next == 0xFFFFFFFFu) {
+                if (sp == 0) break;
+                sp--;
+                next = __builtin_amdgcn_readlane(stack_v, sp);
+              }
+              cur = next;
             }
           }
         } else {
@@ -433,10 +522,16 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
         cand = mt;
         ctri = mk_;
+        TSTAMP(t_mesh1);
+        TACC(1, t_mesh0, t_mesh1);
       } else if (type == CTR_OBJ_PLANE) {
         // ---- plane::intersect, default_schema.hpp:189-201 ----
         const V3 p = mk(O.f[0], O.f[1], O.f[2]), n = mk(O.f[3], O.f[4], O.f[5]);
+#ifdef ABL_PLANES
+        const float num = O.f[0], den = O.f[3] + rd.x;
+#else
         const float num = vdot(vsub(p, ro), n), den = vdot(rd, n);
+#endif
         // The IEEE division is only worth doing where the quotient can matter: skip it (for the
         // whole wave) when a 1-ulp reciprocal already proves t0 < min_t or t0 >= the current bound.
         const float ta = num * __builtin_amdgcn_rcpf(den);
@@ -488,6 +583,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       }
     }
     const bool was_hit = bobj >= 0;
+    TSTAMP(t_loop1);
+    TACC(0, t_loop0, t_loop1);
 
     // =====================================================================
     // continuation: what did this lane cast the ray for?
@@ -551,7 +648,11 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         done_shadow = true;
       }
       if (done_shadow) {
+#ifdef ABL_SHADE
+        if (false) {
+#else
         if (shadow_fac < 1.0f) {
+#endif
           // shading.hpp:86-95
           const CADDR DMat &M = A.mats[mat_i];
           const CADDR DLight &Lg = A.lights[li];
@@ -666,6 +767,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         }
       }
     }
+    TSTAMP(t_cont1);
+    TACC(2, t_loop1, t_cont1);
   }
 #undef STK
 
@@ -687,6 +790,12 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     if (STATS && lane == 0) {
       for (int q = 0; q < 6; q++) atomicAdd(&sh[4 + q], st[q]);
     }
+#ifdef CTR_TIMING
+    if (lane == 0) {
+      tm[3] = __builtin_readcyclecounter() - tm_start;
+      for (int q = 0; q < 4; q++) atomicAdd(&sh[10 + q], tm[q]);
+    }
+#endif
     if (lane == 0) {
       atomicAdd(&sh[0], c);
       atomicMax(&sh[1], (unsigned long long)dbits);
@@ -703,7 +812,7 @@ __global__ __launch_bounds__(256) void fold_shards(unsigned long long *__restric
   __syncthreads();
   for (uint32_t sidx = threadIdx.x; sidx < CTR_SHARDS; sidx += blockDim.x) {
     unsigned long long *sh = shards + (size_t)sidx * CTR_SHARD_WORDS;
-    for (int q = 0; q < 10; q++) {
+    for (int q = 0; q < 14; q++) {
       const unsigned long long v = sh[q];
       if (v) {
         if (q == 1) atomicMax(&acc[q], v); else atomicAdd(&acc[q], v);
@@ -712,7 +821,7 @@ __global__ __launch_bounds__(256) void fold_shards(unsigned long long *__restric
     }
   }
   __syncthreads();
-  if (threadIdx.x < 10) {
+  if (threadIdx.x < 14) {
     const unsigned long long v = acc[threadIdx.x];
     if (v) {
       if (threadIdx.x == 1) atomicMax(&out[1], v); else atomicAdd(&out[threadIdx.x], v);

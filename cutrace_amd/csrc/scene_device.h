@@ -9,7 +9,7 @@
 //                           per mesh in BVH-leaf order, each carrying its ORIGINAL file
 //                           index (ties on t are broken by it, so results do not depend
 //                           on the order); then stand-alone triangles
-//   DNode  nodes[n_node]    64 B records, per-mesh BVH in pre-order with skip links (bvh.h)
+//   DNode  nodes[n_node]    64 B records, per-mesh BVH, inner nodes holding both children's boxes (bvh.h)
 //   float4 gnorm[n_tri]     geometric normal of each DTri as the reference computes it on
 //                           a hit; only the winning triangle's is ever fetched
 //   DLight lights[n_light]  32 B
@@ -44,12 +44,13 @@ struct DObj {
   uint32_t tri_begin;   // mesh: first DTri; triangle: its DTri
   uint32_t tri_count;   // mesh: number of triangles; triangle: 1
   uint32_t node_begin;  // mesh: first DNode of its BVH
-  uint32_t node_count;  // mesh: number of BVH nodes
+  uint32_t node_count;  // mesh: number of (inner) BVH nodes
+  uint32_t bvh_root;    // mesh: descriptor of the root (bvh.h)
   // triangle: unused
   // mesh    : f[0..2] bbox.min, f[3..5] bbox.max
   // plane   : f[0..2] point,    f[3..5] normal
   // sphere  : f[0..2] center,   f[3] radius, f[4] radius*radius
-  float f[10];
+  float f[9];
 };
 static_assert(sizeof(DObj) == 64, "DObj must be 64 bytes");
 

@@ -34,6 +34,9 @@ def main():
         env = dict(os.environ, CUTRACE_AMD_LIB=lib)
         r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
         line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]
+        for el in r.stderr.splitlines():
+            if "timing" in el:
+                print("   ", el, flush=True)
         print(f"{name:28s} {flags:60s} {line}", flush=True)
         os.remove(lib)
 if __name__ == "__main__":
