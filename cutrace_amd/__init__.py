@@ -22,6 +22,8 @@ VAR_NO_ANYHIT = 4
 VAR_NO_CLUSTER = 8
 VAR_STATS = 16
 VAR_EXACT_POW = 32
+VAR_VMEM = 64
+VAR_SMEM = 128
 
 
 @contextlib.contextmanager

@@ -43,6 +43,7 @@
 
 #define CADDR __attribute__((address_space(4)))
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
+#define HIDE_UNIFORM(x) asm volatile("" : "+v"(x))  /* make a wave-uniform index look per-lane: vector load */
 #define PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))  /* opaque to LICM / speculation */
 #define INVB(m) __builtin_amdgcn_inverse_ballot_w64(m)   /* wave-uniform lane mask -> per-lane predicate */
 #define FCMP(a, b, pred) __builtin_amdgcn_fcmpf((a), (b), (pred))  /* v_cmp straight into a lane mask */
@@ -58,6 +59,9 @@ namespace {
 #endif
 #ifndef CTR_WAVES_PER_WG
 #define CTR_WAVES_PER_WG 1
+#endif
+#ifndef CTR_LEAF_UNROLL
+#define CTR_LEAF_UNROLL 1
 #endif
 #ifndef CTR_WHOLE_OBJ
 #define CTR_WHOLE_OBJ 0
@@ -126,6 +130,8 @@ struct KArgs {
   const CADDR DObj *objs;
   const CADDR DTri *tris;
   const CADDR DNode *nodes;
+  const DTri *tris_g;          // the same arrays through the global address space (VMEM variant)
+  const DNode *nodes_g;
   const CADDR float *gnorm;
   const CADDR DLight *lights;
   const CADDR DMat *mats;
@@ -157,6 +163,11 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   constexpr bool BVH = (KV & KV_BVH) != 0;
   constexpr bool STATS = (KV & KV_STATS) != 0;
   constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
+  // VMEM: BVH nodes and triangles travel through the vector memory path (same address in every
+  // lane, values in VGPRs) instead of the scalar cache.  The scalar cache sustains very few
+  // outstanding misses: past a few hundred KB of mesh data its miss queue, not arithmetic, sets
+  // the frame time (64k-triangle bunny: 76 ms scalar vs the vector path).
+  constexpr bool VMEM = (KV & KV_VMEM) != 0;
   // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
@@ -257,11 +268,16 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     bool live = active;  // lanes still searching (any-hit mode retires occluded lanes)
     V3 rinv = mk(0, 0, 0);     // exact 1/dir (IEEE divisions), computed lazily: see the mesh branch
     bool have_rinv = false;    // wave-uniform
-    V3 ria = mk(0, 0, 0), roi = mk(0, 0, 0);
+    V3 ria = mk(0, 0, 0);
+    float ria_big = 0.f;
     float cmax = 0.f;
     if (A.has_mesh) {
-      ria = mk(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));  // 1 ulp
-      roi = mk(ro.x * ria.x, ro.y * ria.y, ro.z * ria.z);  // box tests as fma(b, 1/d, -o/d)
+      // 1-ulp reciprocals, clamped to +-1e30: an axis-parallel ray (d = 0 -> inf) then gives huge
+      // FINITE slab distances with the right signs instead of inf - inf = NaN
+      ria = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(rd.x), -1e30f), 1e30f),
+               fminf(fmaxf(__builtin_amdgcn_rcpf(rd.y), -1e30f), 1e30f),
+               fminf(fmaxf(__builtin_amdgcn_rcpf(rd.z), -1e30f), 1e30f));
+      ria_big = fmaxf(fmaxf(fabsf(ria.x), fabsf(ria.y)), fabsf(ria.z));
       cmax = fmaxf(fmaxf(fabsf(rd.x), fabsf(rd.y)), fabsf(rd.z));
     }
 
@@ -308,8 +324,10 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           const float dl = tabs * 0x1p-20f;
           const mask_t def_hit = FCMP(lo_a + dl, hi_a, FC_OLT);
           const mask_t def_miss = FCMP(lo_a - dl, hi_a, FC_OGT);
-          const mask_t border = live_m & ~(def_hit | def_miss);
-          bb_m = live_m & def_hit;
+          // axis-parallel rays always take the exact path: the reference's inf/NaN min/max semantics
+          // (0 x inf when the origin sits exactly on a box face) are not what finite arithmetic gives
+          const mask_t border = live_m & (~(def_hit | def_miss) | FCMP(ria_big, 1e29f, FC_OGE));
+          bb_m = live_m & def_hit & ~border;
           if (border != 0ull) {
             if (!have_rinv) {  // wave-uniform: the exact reciprocals are computed at most once per cast
               float ox = rd.x, oy = rd.y, oz = rd.z;
@@ -441,12 +459,17 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           // first.  The box test is conservative: boxes are widened by m = 2^-15 x (largest
           // |coordinate difference| between the ray origin and the mesh), applied in t-space as a
           // slack of 2*m*max|1/dir|; a NaN enters the box.
+          // The box test is conservative: every box is widened in WORLD space by
+          //   m = 2^-14 x (largest |coordinate difference| between the ray origin and the mesh box)
+          // per axis ((mn - m - o)/d and (mx + m - o)/d, folded into the two FMA constants below), far
+          // above the rounding of either this test or the reference's triangle test (DESIGN.md
+          // §bvh); a NaN (0 x inf for an axis-parallel ray) drops that axis' constraint.
           const float gx = fmaxf(fabsf(O.f[0] - ro.x), fabsf(O.f[3] - ro.x));
           const float gy = fmaxf(fabsf(O.f[1] - ro.y), fabsf(O.f[4] - ro.y));
           const float gz = fmaxf(fabsf(O.f[2] - ro.z), fabsf(O.f[5] - ro.z));
-          const float slack = (fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f) *
-                              fmaxf(fmaxf(fabsf(ria.x), fabsf(ria.y)), fabsf(ria.z));
-          const float min_ts = min_t - slack;
+          const float mw = fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f;
+          const V3 ka = mk((ro.x + mw) * ria.x, (ro.y + mw) * ria.y, (ro.z + mw) * ria.z);  // for box minima
+          const V3 kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);  // for box maxima
           const CADDR DNode *nodes = A.nodes + O.node_begin;
           // direction signs of the first lane that needs the mesh decide the visiting order (speed only)
           const uint32_t lead = (uint32_t)__builtin_ctzll(bb_m);
@@ -454,18 +477,30 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
                                     ((__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31) << 1) |
                                     ((__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31) << 2);
           auto box_hits = [&](const auto &mn, const auto &mx) -> mask_t {
-            const float t1x = __builtin_fmaf(mn[0], ria.x, -roi.x), t2x = __builtin_fmaf(mx[0], ria.x, -roi.x);
-            const float t1y = __builtin_fmaf(mn[1], ria.y, -roi.y), t2y = __builtin_fmaf(mx[1], ria.y, -roi.y);
-            const float t1z = __builtin_fmaf(mn[2], ria.z, -roi.z), t2z = __builtin_fmaf(mx[2], ria.z, -roi.z);
-            const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z)) - slack;
+            const float t1x = __builtin_fmaf(mn[0], ria.x, -ka.x), t2x = __builtin_fmaf(mx[0], ria.x, -kb.x);
+            const float t1y = __builtin_fmaf(mn[1], ria.y, -ka.y), t2y = __builtin_fmaf(mx[1], ria.y, -kb.y);
+            const float t1z = __builtin_fmaf(mn[2], ria.z, -ka.z), t2z = __builtin_fmaf(mx[2], ria.z, -kb.z);
+            const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
             const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
             // reject only on a definite miss (NaN compares false -> the box is entered)
-            const mask_t miss = FCMP(lo, hi, FC_OGT) | FCMP(hi, min_ts, FC_OLT) | FCMP(lo, lim, FC_OGT);
+            const mask_t miss = FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, lim, FC_OGT);
             return bb_m & ~miss;
           };
           auto leaf = [&](uint32_t desc, mask_t lanes) {
             const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
-            for (uint32_t k = 0; k < n_l; ++k) tri_test(A.tris[first + k], first + k, lanes & bb_m);
+#if CTR_LEAF_UNROLL > 1
+#pragma unroll CTR_LEAF_UNROLL
+#endif
+            for (uint32_t k = 0; k < n_l; ++k) {
+              if (VMEM) {
+                uint32_t iv = first + k;
+                HIDE_UNIFORM(iv);
+                const DTri Tv = A.tris_g[iv];
+                tri_test(Tv, first + k, lanes & bb_m);
+              } else {
+                tri_test(A.tris[first + k], first + k, lanes & bb_m);
+              }
+            }
           };
           uint32_t cur = O.bvh_root;
           if (cur & BVH_LEAF_FLAG) {
@@ -474,12 +509,27 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             uint32_t stack_v = 0;  // lane k of this VGPR = stack slot k (depth <= BVH_MAX_DEPTH < 64)
             uint32_t sp = 0;
             for (;;) {
-              const CADDR DNode &N = nodes[cur];
               if (STATS) st[1]++;
+              mask_t hl, hr;
+              uint32_t n_left, n_right, n_axis;
+              if (VMEM) {
+                uint32_t cv = O.node_begin + cur;
+                HIDE_UNIFORM(cv);
+                const DNode Nv = A.nodes_g[cv];
+                hl = box_hits(Nv.lmn, Nv.lmx);
+                hr = box_hits(Nv.rmn, Nv.rmx);
+                n_left = __builtin_amdgcn_readfirstlane(Nv.left);
+                n_right = __builtin_amdgcn_readfirstlane(Nv.right);
+                n_axis = __builtin_amdgcn_readfirstlane(Nv.axis);
+              } else {
+                const CADDR DNode &N = nodes[cur];
+                hl = box_hits(N.lmn, N.lmx);
+                hr = box_hits(N.rmn, N.rmx);
+                n_left = N.left; n_right = N.right; n_axis = N.axis;
+              }
               // near child first
-              const bool swap = ((neg_bits >> N.axis) & 1u) != 0u;
-              const mask_t hl = box_hits(N.lmn, N.lmx), hr = box_hits(N.rmn, N.rmx);
-              const uint32_t d0 = swap ? N.right : N.left, d1 = swap ? N.left : N.right;
+              const bool swap = ((neg_bits >> n_axis) & 1u) != 0u;
+              const uint32_t d0 = swap ? n_right : n_left, d1 = swap ? n_left : n_right;
               const mask_t h0 = swap ? hr : hl, h1 = swap ? hl : hr;
               uint32_t next = 0xFFFFFFFFu;
               if (h0 != 0ull) {
@@ -835,6 +885,8 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.objs = (const CADDR DObj *)L.objs;
   A.tris = (const CADDR DTri *)L.tris;
   A.nodes = (const CADDR DNode *)L.nodes;
+  A.tris_g = L.tris;
+  A.nodes_g = (const DNode *)L.nodes;
   A.gnorm = (const CADDR float *)L.gnorm;
   A.lights = (const CADDR DLight *)L.lights;
   A.mats = (const CADDR DMat *)L.mats;
@@ -897,5 +949,14 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
   if (L.variant & KV_STATS)
     return (L.variant & KV_ANYHIT) ? launch<KV_BVH | KV_PREFILTER | KV_ANYHIT | KV_FASTPOW | KV_STATS>(L, s)
                                    : launch<KV_BVH | KV_PREFILTER | KV_FASTPOW | KV_STATS>(L, s);
+  if ((L.variant & KV_VMEM) && (L.variant & KV_BVH) && (L.variant & KV_PREFILTER)) {
+    constexpr uint32_t B = KV_VMEM | KV_BVH | KV_PREFILTER;
+    switch (L.variant & (KV_ANYHIT | KV_FASTPOW)) {
+      case 0: return launch<B>(L, s);
+      case KV_ANYHIT: return launch<B | KV_ANYHIT>(L, s);
+      case KV_FASTPOW: return launch<B | KV_FASTPOW>(L, s);
+      default: return launch<B | KV_ANYHIT | KV_FASTPOW>(L, s);
+    }
+  }
   return (L.variant & KV_FASTPOW) ? launch_main<KV_FASTPOW>(L, s) : launch_main<0>(L, s);
 }

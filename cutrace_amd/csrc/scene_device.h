@@ -83,6 +83,7 @@ enum : uint32_t {
   KV_BVH = 8u,         // walk each mesh through its BVH instead of linearly
   KV_STATS = 16u,      // diagnostic: wave-level work counters into counters[4..9]
   KV_FASTPOW = 32u,    // specular pow() as exp2(e*log2(x)) in f32 instead of f64 pow
+  KV_VMEM = 64u,       // mesh data through the vector memory path instead of the scalar cache
 };
 
 struct DRows {

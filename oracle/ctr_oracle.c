@@ -23,6 +23,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -71,6 +72,8 @@ typedef struct {
   const ctr_scene_desc *s;
   uint64_t casts;       /* ray_cast invocations */
   uint64_t alg_bytes;   /* SURVEY §8(d) algorithmic bytes of those casts */
+  int trace;            /* debugging aid: print every cast (orc_trace_pixel) */
+  int64_t last_tri;     /* index (within the mesh) of the triangle that won the last mesh_intersect */
 } octx;
 
 /* ---- inc/default_schema.hpp primitives ------------------------------------ */
@@ -118,6 +121,7 @@ static int mesh_intersect(octx *cx, const ctr_object *o, const ray *r, float min
       *dist = t;
       *hit = h;
       *normal = n;
+      cx->last_tri = (int64_t)k;
     }
   }
   return *dist != INFINITY;
@@ -186,6 +190,12 @@ static int ray_cast(octx *cx, const ray *finder, float min_dist, float *distance
         was_hit = 1;
       }
     }
+  }
+  if (cx->trace) {
+    printf("cast o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) min=%.9g -> hit=%d obj=%lld tri=%lld t=%.9g\n", finder->start.x,
+           finder->start.y, finder->start.z, finder->dir.x, finder->dir.y, finder->dir.z, min_dist, was_hit,
+           was_hit ? (long long)*hit_id : -1LL,
+           (was_hit && s->objects[*hit_id].type == CTR_OBJ_MESH) ? (long long)cx->last_tri : -1LL, *distance);
   }
   return was_hit;
 }
@@ -314,7 +324,7 @@ typedef struct {
 
 static void *worker(void *arg) {
   job *j = (job *)arg;
-  octx cx = {j->s, 0, 0};
+  octx cx = {j->s, 0, 0, 0, -1};
   uint64_t w = j->s->cam.w;
   for (;;) {
     uint64_t k = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
@@ -368,6 +378,16 @@ int orc_render(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows
   if (counters) { counters[0] = casts; counters[1] = bytes + 28ull * n * s->cam.w; }
   free(jobs); free(th); free(sel);
   return 0;
+}
+
+/* debugging aid: print every ray_cast of one pixel (origin, direction, winner) */
+void orc_trace_pixel(const ctr_scene_desc *s, uint64_t x, uint64_t y, float fudge, int bounces) {
+  octx cx = {s, 0, 0, 1, -1};
+  float depth;
+  vec color, normal;
+  render_pixel(&cx, x, y, fudge, bounces, &depth, &color, &normal, 0, 0);
+  printf("pixel (%llu,%llu): depth=%.9g color=(%.9g %.9g %.9g) casts=%llu\n", (unsigned long long)x,
+         (unsigned long long)y, depth, color.x, color.y, color.z, (unsigned long long)cx.casts);
 }
 
 /* cam::look_at restated for the oracle's own use (default_schema.hpp:370-374) */

@@ -1,5 +1,5 @@
 import sys, os, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cutrace_amd as ca
 dev = torch.device("cuda:0")

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cutrace_amd as ca
 for name, b in (("bunny", 5), ("mirror", 8), ("sphere_plane", 5)):
     s = ca.HostScene.load(f"scene/{name}.json")
