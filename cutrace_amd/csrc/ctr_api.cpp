@@ -49,7 +49,7 @@ inline f3 cross(f3 a, f3 o) { return {a.y * o.z - a.z * o.y, a.z * o.x - a.x * o
 #define CTR_VMEM_THRESHOLD (128 * 1024)
 #endif
 #ifndef CTR_BVH_LEAF
-#define CTR_BVH_LEAF 8
+#define CTR_BVH_LEAF 4
 #endif
 constexpr uint32_t BVH_LEAF = CTR_BVH_LEAF;  // triangles per BVH leaf
 

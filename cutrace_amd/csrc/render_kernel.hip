@@ -70,7 +70,7 @@ namespace {
 #define CTR_PREFETCH 0
 #endif
 #ifndef CTR_TILE_STRIDE
-#define CTR_TILE_STRIDE 1
+#define CTR_TILE_STRIDE 0
 #endif
 #ifndef CTR_MIN_WAVES_EU
 #define CTR_MIN_WAVES_EU 4

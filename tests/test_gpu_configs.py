@@ -75,6 +75,34 @@ def test_c4_bunny_grid(ca, gen_dir):
         assert same_bits(pr["color"], full["color"][ys]) and same_bits(pr["depth"], full["depth"][ys])
 
 
+def test_axis_parallel_rays_through_meshes(ca):
+    """Rays with an exactly-zero direction component (centre row/column of an axis-aligned camera,
+    shadow rays at a light's height) take the inf/NaN paths of every slab test: they must still give
+    the reference's result, through the BVH as well as the linear walk."""
+    import json
+    sc = {
+        "camera": {"eye": [0, 0, 3], "up": [0, 1, 0], "look": [0, 0, 0], "near_plane": 0.1, "far_plane": 10,
+                   "width": 64, "height": 64, "ambient": 0.05},
+        "lights": [{"type": "point", "point": [0, 0, 2.5]}, {"type": "sun", "direction": [0, -1, 0]},
+                   {"type": "point", "point": [0.7431471, 0.5, 0.0]}],
+        "materials": [{"type": "solid", "color": [0.8, 0.8, 0.8], "reflect": 0.3},
+                      {"type": "solid", "color": [0.2, 0.5, 0.9], "reflect": 0.5}],
+        "objects": [{"type": "mesh", "file": "scene/bunny.stl", "material": 0},
+                    {"type": "mesh", "file": "scene/frame.stl", "material": 1},
+                    {"type": "plane", "point": [0, -0.7391002, 0], "normal": [0, 1, 0], "material": 1},
+                    {"type": "plane", "point": [-1, 0, 0], "normal": [1, 0, 0], "material": 1}],
+    }
+    s = ca.HostScene.parse(json.dumps(sc))
+    assert s.ok
+    o = ca.oracle_render(s, bounces=4, threads=NT)
+    ds = ca.DeviceScene(s)
+    for variant in (ca.VAR_EXACT_POW, ca.VAR_EXACT_POW | ca.VAR_NO_CLUSTER, ca.VAR_EXACT_POW | ca.VAR_VMEM, 0):
+        ds.set_variant(variant)
+        r = ds.render(bounces=4)
+        assert_parity(r, o, what=f"axis-parallel variant {variant}")
+        assert r["ray_count"] == o["ray_count"]
+
+
 def test_cli_drop_in(ca, tmp_path):
     """`cutrace <scene.json>`: same stdout lines and the three JPGs of the reference CLI (main.cu:8-47)."""
     from PIL import Image
