@@ -854,27 +854,38 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   }
 }
 
-// one block: adds the shards into out[0..15] (max for word 1) and zeroes them for the next launch
-__global__ __launch_bounds__(256) void fold_shards(unsigned long long *__restrict__ shards,
-                                                   unsigned long long *__restrict__ out) {
-  __shared__ unsigned long long acc[CTR_SHARD_WORDS];
-  if (threadIdx.x < CTR_SHARD_WORDS) acc[threadIdx.x] = 0ull;
+// one block of CTR_SHARDS threads: thread t owns shard t; wave-level reduction, then one LDS atomic per
+// wave and word; adds into out[0..13] (max for word 1) and zeroes the shards for the next launch
+__global__ __launch_bounds__(CTR_SHARDS) void fold_shards(unsigned long long *__restrict__ shards,
+                                                          unsigned long long *__restrict__ out) {
+  constexpr int NW = 14;
+  __shared__ unsigned long long acc[NW];
+  if (threadIdx.x < NW) acc[threadIdx.x] = 0ull;
   __syncthreads();
-  for (uint32_t sidx = threadIdx.x; sidx < CTR_SHARDS; sidx += blockDim.x) {
-    unsigned long long *sh = shards + (size_t)sidx * CTR_SHARD_WORDS;
-    for (int q = 0; q < 14; q++) {
-      const unsigned long long v = sh[q];
-      if (v) {
-        if (q == 1) atomicMax(&acc[q], v); else atomicAdd(&acc[q], v);
-        sh[q] = 0ull;
-      }
+  unsigned long long *sh = shards + (size_t)threadIdx.x * CTR_SHARD_WORDS;
+  unsigned long long v[NW];
+#pragma unroll
+  for (int q = 0; q < NW; q++) {
+    v[q] = sh[q];
+    if (v[q]) sh[q] = 0ull;
+  }
+#pragma unroll
+  for (int q = 0; q < NW; q++) {
+    unsigned long long x = v[q];
+    if (__builtin_amdgcn_ballot_w64(x != 0ull) == 0ull) continue;  // word unused by this build (wave-uniform)
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(x, off);
+      x = (q == 1) ? (o > x ? o : x) : x + o;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (q == 1) atomicMax(&acc[q], x); else atomicAdd(&acc[q], x);
     }
   }
   __syncthreads();
-  if (threadIdx.x < 14) {
-    const unsigned long long v = acc[threadIdx.x];
-    if (v) {
-      if (threadIdx.x == 1) atomicMax(&out[1], v); else atomicAdd(&out[threadIdx.x], v);
+  if (threadIdx.x < NW) {
+    const unsigned long long r = acc[threadIdx.x];
+    if (r) {
+      if (threadIdx.x == 1) atomicMax(&out[1], r); else atomicAdd(&out[threadIdx.x], r);
     }
   }
 }
@@ -923,7 +934,7 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   unsigned long long *shards = L.counters ? L.shards : nullptr;
   hipLaunchKernelGGL(render_kernel<KV>, dim3(grid), dim3(WG_THREADS), lds_bytes, stream, A, L.depth, L.color, L.normal,
                      shards);
-  if (shards) hipLaunchKernelGGL(fold_shards, dim3(1), dim3(256), 0, stream, shards, L.counters);
+  if (shards) hipLaunchKernelGGL(fold_shards, dim3(1), dim3(CTR_SHARDS), 0, stream, shards, L.counters);
   return (int)hipGetLastError();
 }
 
