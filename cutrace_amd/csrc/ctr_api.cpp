@@ -93,6 +93,9 @@ void make_tri(const ctr_vec3 &p1, const ctr_vec3 &p2, const ctr_vec3 &p3, uint32
 struct ctr_scene {
   int device = 0;
   DObj *d_objs = nullptr;
+  DObj *d_oloop = nullptr;
+  DPlane *d_planes = nullptr;
+  uint32_t n_oloop = 0, n_planes = 0;
   DTri *d_tris = nullptr;
   DNode *d_nodes = nullptr;
   float *d_gnorm = nullptr;
@@ -174,6 +177,10 @@ int make_rows(const ctr_scene *s, const ctr_rows *rin, DRows &R) {
 
 void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.objs = s->d_objs;
+  L.oloop = s->d_oloop;
+  L.planes = s->d_planes;
+  L.n_oloop = s->n_oloop;
+  L.n_planes = s->n_planes;
   L.tris = s->d_tris;
   L.nodes = s->d_nodes;
   L.gnorm = s->d_gnorm;
@@ -269,6 +276,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     memset(&O, 0, sizeof(O));
     O.type = o.type;
     O.mat = (uint32_t)o.mat_idx;
+    O.index = (uint32_t)i;
     switch (o.type) {
       case CTR_OBJ_TRIANGLE: {
         O.tri_begin = (uint32_t)tris.size();
@@ -325,6 +333,12 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         break;
     }
   }
+  std::vector<DObj> oloop;
+  std::vector<DPlane> planes;
+  for (const DObj &O : objs) {
+    if (O.type == CTR_OBJ_PLANE) planes.push_back(DPlane{O.f[0], O.f[1], O.f[2], O.f[3], O.f[4], O.f[5], O.index, O.mat});
+    else oloop.push_back(O);
+  }
   std::vector<DLight> lights(d->n_lights);
   for (uint64_t i = 0; i < d->n_lights; i++) {
     const ctr_light &l = d->lights[i];
@@ -360,7 +374,11 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     return er;
   };
   hipError_t er;
+  s->n_oloop = (uint32_t)oloop.size();
+  s->n_planes = (uint32_t)planes.size();
   if ((er = upload((void **)&s->d_objs, objs.data(), objs.size() * sizeof(DObj))) != hipSuccess ||
+      (er = upload((void **)&s->d_oloop, oloop.data(), oloop.size() * sizeof(DObj))) != hipSuccess ||
+      (er = upload((void **)&s->d_planes, planes.data(), planes.size() * sizeof(DPlane))) != hipSuccess ||
       (er = upload((void **)&s->d_tris, tris.data(), tris.size() * sizeof(DTri))) != hipSuccess ||
       (er = upload((void **)&s->d_nodes, nodes.data(), nodes.size() * sizeof(DNode))) != hipSuccess ||
       (er = upload((void **)&s->d_gnorm, gn.data(), gn.size() * sizeof(float))) != hipSuccess ||
@@ -405,7 +423,7 @@ int ctr_scene_set_cameras(ctr_scene *s, const ctr_camera *cams, uint32_t n) {
 void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void *p : {(void *)s->d_objs, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
+  for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
                   (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters, (void *)s->d_shards})
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);

@@ -127,7 +127,10 @@ __device__ __forceinline__ T ldc(const CADDR T *p) {
 }
 
 struct KArgs {
-  const CADDR DObj *objs;
+  const CADDR DObj *objs;      // every object in scene order (hit records)
+  const CADDR DObj *oloop;     // non-plane objects (generic loop)
+  const CADDR DPlane *planes;
+  uint32_t n_oloop, n_planes;
   const CADDR DTri *tris;
   const CADDR DNode *nodes;
   const DTri *tris_g;          // the same arrays through the global address space (VMEM variant)
@@ -282,21 +285,47 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     }
 
     TSTAMP(t_loop0);
-#if CTR_PREFETCH
-    // software pipeline of the wave-uniform record loads: object i+1 is requested before object i is
-    // processed (scalar loads return out of order, so the wait for record i must come BEFORE the next
-    // request is issued — copying it into `O` does that)
-    DObj o_next = ldc(&A.objs[0]);  // the array always holds at least one (possibly unused) record
-#endif
-    for (uint32_t i = 0; i < A.n_obj; ++i) {
-#if CTR_PREFETCH
-      const DObj O = o_next;
-      if (i + 1 < A.n_obj) o_next = ldc(&A.objs[i + 1]);
-#elif CTR_WHOLE_OBJ
-      const DObj O = ldc(&A.objs[i]);  // one 64-byte request instead of type-then-payload (two latencies)
-#else
-      const CADDR DObj &O = A.objs[i];
-#endif
+    typedef unsigned long long mask_t;
+    const bool anyhit_cast = ANYHIT && shadow_cast;
+    // ---- planes: plane::intersect, default_schema.hpp:189-201, all in lane masks ----
+    {
+      mask_t live_m = BALLOT(live);
+      for (uint32_t p = 0; p < A.n_planes; ++p) {
+        const CADDR DPlane &P = A.planes[p];
+        const V3 pp = mk(P.px, P.py, P.pz), n = mk(P.nx, P.ny, P.nz);
+        const float num = vdot(vsub(pp, ro), n), den = vdot(rd, n);
+        // The IEEE division is only worth doing where the quotient can matter: skip it (for the
+        // whole wave) when a 1-ulp reciprocal already proves t0 < min_t or t0 >= the current bound.
+        const float ta = num * __builtin_amdgcn_rcpf(den);
+        const float mrg = fabsf(ta) * 0x1p-18f + 1e-30f;
+        const float lim_hi = anyhit_cast ? light_dist : best;
+        const mask_t need_m = live_m & ~(FCMP(ta + mrg, min_t, FC_OLT) | FCMP(ta - mrg, lim_hi, FC_OGT));  // NaN/inf -> needed
+        if (need_m == 0ull) continue;
+        bool retire = false;
+        if (INVB(need_m)) {
+          const float t0 = num / den;
+          // isfinite && min_t <= t0 (plane) && t0 > min_t (ray_cast.hpp:43)  ==  finite && t0 > min_t
+          if (__builtin_isfinite(t0) && t0 > min_t) {
+            // ray_cast.hpp:43: strict <, first object in scene order wins ties
+            const uint32_t pidx = P.index;
+            if (t0 < best || (t0 == best && (int)pidx < bobj)) { best = t0; bobj = (int)pidx; btri = -1; }
+            if (anyhit_cast && t0 < light_dist) retire = true;
+          }
+        }
+        if (ANYHIT) {
+          live_m &= ~BALLOT(retire);
+          if (live_m == 0ull) break;
+        }
+      }
+      if (ANYHIT) live = INVB(live_m);
+    }
+    // ---- every other object, scene order ----
+    for (uint32_t oi = 0; oi < A.n_oloop; ++oi) {
+      if (ANYHIT) {
+        if (BALLOT(live) == 0ull) break;
+      }
+      const CADDR DObj &O = A.oloop[oi];
+      const uint32_t i = O.index;
       const uint32_t type = O.type;
       bool ok = false;
       float cand = INFINITY;
@@ -304,7 +333,6 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       if (type == CTR_OBJ_MESH) {
         // Everything in this branch works on 64-bit lane masks (v_cmp results kept in SGPRs and
         // combined on the scalar unit) instead of per-lane booleans.
-        typedef unsigned long long mask_t;
         TSTAMP(t_mesh0);
         const mask_t live_m = BALLOT(live);
         // ---- mesh::bound_intersects, default_schema.hpp:99-114 ----
@@ -574,25 +602,6 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         ctri = mk_;
         TSTAMP(t_mesh1);
         TACC(1, t_mesh0, t_mesh1);
-      } else if (type == CTR_OBJ_PLANE) {
-        // ---- plane::intersect, default_schema.hpp:189-201 ----
-        const V3 p = mk(O.f[0], O.f[1], O.f[2]), n = mk(O.f[3], O.f[4], O.f[5]);
-#ifdef ABL_PLANES
-        const float num = O.f[0], den = O.f[3] + rd.x;
-#else
-        const float num = vdot(vsub(p, ro), n), den = vdot(rd, n);
-#endif
-        // The IEEE division is only worth doing where the quotient can matter: skip it (for the
-        // whole wave) when a 1-ulp reciprocal already proves t0 < min_t or t0 >= the current bound.
-        const float ta = num * __builtin_amdgcn_rcpf(den);
-        const float mrg = fabsf(ta) * 0x1p-18f + 1e-30f;
-        const float lim_hi = (ANYHIT && shadow_cast) ? light_dist : best;
-        const bool need = live && !(((ta + mrg) < min_t) | ((ta - mrg) >= lim_hi));  // NaN/inf -> needed
-        if (BALLOT(need) != 0ull) {
-          const float t0 = num / den;
-          ok = need && __builtin_isfinite(t0) && min_t <= t0;
-          cand = t0;
-        }
       } else if (type == CTR_OBJ_SPHERE) {
         // ---- sphere::intersect, default_schema.hpp:226-251 ----
         float sx_ = rd.x, sy_ = rd.y, sz_ = rd.z;
@@ -621,15 +630,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         cand = t0;
         ctri = (int)O.tri_begin;
       }
-      // ray_cast.hpp:43 — first object wins ties (strict <)
-      if (live && ok && cand > min_t && cand < best) {
+      // ray_cast.hpp:43 — strict <, first object in scene order wins ties
+      if (live && ok && cand > min_t && (cand < best || (cand == best && (int)i < bobj))) {
         best = cand;
         bobj = (int)i;
         btri = ctri;
       }
       if (ANYHIT) {
         if (shadow_cast && live && ok && cand > min_t && cand < light_dist) live = false;
-        if (BALLOT(live) == 0ull) break;
       }
     }
     const bool was_hit = bobj >= 0;
@@ -894,6 +902,10 @@ template <uint32_t KV>
 int launch(const RenderLaunch &L, hipStream_t stream) {
   KArgs A;
   A.objs = (const CADDR DObj *)L.objs;
+  A.oloop = (const CADDR DObj *)L.oloop;
+  A.planes = (const CADDR DPlane *)L.planes;
+  A.n_oloop = L.n_oloop;
+  A.n_planes = L.n_planes;
   A.tris = (const CADDR DTri *)L.tris;
   A.nodes = (const CADDR DNode *)L.nodes;
   A.tris_g = L.tris;

@@ -46,13 +46,24 @@ struct DObj {
   uint32_t node_begin;  // mesh: first DNode of its BVH
   uint32_t node_count;  // mesh: number of (inner) BVH nodes
   uint32_t bvh_root;    // mesh: descriptor of the root (bvh.h)
+  uint32_t index;       // position in the scene's object list (hit_id; ties on t go to the lower index)
   // triangle: unused
   // mesh    : f[0..2] bbox.min, f[3..5] bbox.max
   // plane   : f[0..2] point,    f[3..5] normal
   // sphere  : f[0..2] center,   f[3] radius, f[4] radius*radius
-  float f[9];
+  float f[8];
 };
 static_assert(sizeof(DObj) == 64, "DObj must be 64 bytes");
+
+// planes get their own dense array and loop (one 32-byte s_load_dwordx8 each, no type dispatch):
+// box scenes are mostly planes, and every cast visits every one of them
+struct DPlane {
+  float px, py, pz;     // point
+  float nx, ny, nz;     // normal
+  uint32_t index;       // position in the scene's object list
+  uint32_t mat;
+};
+static_assert(sizeof(DPlane) == 32, "DPlane must be 32 bytes");
 
 struct DLight {
   uint32_t type;        // CTR_LIGHT_*
@@ -97,7 +108,10 @@ struct DRows {
 };
 
 struct RenderLaunch {
-  const DObj *objs;
+  const DObj *objs;        // every object, scene order (hit records)
+  const DObj *oloop;       // the non-plane objects, scene order (the generic loop)
+  const DPlane *planes;
+  uint32_t n_oloop, n_planes;
   const DTri *tris;
   const void *nodes;    // DNode[] (bvh.h)
   const float *gnorm;   // 4 floats per triangle
