@@ -694,7 +694,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       bool done_shadow;
       float shadow_fac = 0.f;
       if (was_hit && best < light_dist) {
-        const float trans = A.mats[A.objs[bobj].mat].transparency;
+        // scenes without any transparency (the any-hit builds) need no material lookup here
+        const float trans = ANYHIT ? 0.0f : A.mats[A.objs[bobj].mat].transparency;
         intensity += (1.0f - trans);
         if (intensity >= 1.0f) { shadow_fac = 1.0f; done_shadow = true; }
         else {
