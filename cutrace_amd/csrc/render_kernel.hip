@@ -7,32 +7,36 @@
 //   triangle/mesh/plane/sphere::intersect, lights, material, cam::get_ray
 //                            inc/default_schema.hpp:22-399
 //
-// Design (MI355X-first, not a translation):
-//  * one lane = one pixel, one wave = a TW x TH pixel tile, so the 64 rays of a wave
-//    are spatially coherent; the scene is tiny and read-only, so EVERY scene read in
-//    the hot loops has a wave-uniform address: objects and mesh triangles are fetched
-//    with scalar loads (s_load_dwordx16 = one 64-byte DTri) into SGPRs and feed the
-//    VALU as scalar operands — no VGPRs, no LDS bandwidth, no bank conflicts.
-//  * the recursion of ray_color (template depth `bounces`) becomes an explicit
-//    per-lane state machine: every trip of the outer loop performs exactly ONE
-//    nearest-hit cast for every live lane, whatever that lane needs it for (primary,
-//    reflection, pass-through or a shadow-loop iteration).  The expensive part (the
-//    object/triangle loops) is therefore always executed by a full, converged wave;
-//    only the cheap continuation logic diverges.
-//  * a mesh is skipped for the whole wave when no lane's ray hits its AABB
-//    (ballot), and inside a mesh a conservative FMA prefilter (31 VALU ops) rejects
-//    triangles for the whole wave; only when some lane survives does the wave run
-//    the reference's exact Cramer/determinant test (default_schema.hpp:57-78), in
-//    the reference's operation order, for the surviving lanes.  The prefilter can
-//    only produce false positives, so results are identical to testing everything.
+// Design (MI355X-first, not a translation; the measurements behind each choice are in DESIGN.md):
+//  * one lane = one pixel, one wave = an 8x8 pixel tile, one wave per workgroup.  The 64 rays of
+//    a wave are spatially coherent and the scene is tiny and read-only, so EVERY scene read in the
+//    hot loops has a wave-uniform address: planes, objects, BVH nodes and triangles are fetched
+//    with scalar loads (one 64-byte record = one s_load_dwordx16) into SGPRs and feed the VALU as
+//    scalar operands — no VGPRs, no LDS bandwidth, no bank conflicts.
+//  * the recursion of ray_color (template depth `bounces`) becomes an explicit per-lane state
+//    machine: every trip of the outer loop performs exactly ONE nearest-hit cast for every live
+//    lane, whatever that lane needs it for (primary, reflection, pass-through or a shadow-loop
+//    iteration).  The expensive part (plane / object / BVH / triangle loops) is always executed by
+//    a converged wave; only the cheap continuation logic diverges.  Suspended activations live in
+//    an LDS stack [frame][field][lane]; no scratch memory.
+//  * hot-loop conditions are 64-bit lane masks (v_cmp into SGPR pairs, combined on the scalar
+//    unit), not per-lane booleans.
+//  * per mesh: the reference's AABB test decided with 1-ulp reciprocals except on borderline lanes;
+//    a BVH (inner nodes hold both children's boxes, wave-uniform stack in the lanes of one VGPR)
+//    walked by the whole wave; per triangle a conservative FMA prefilter (31 VALU ops) for the
+//    whole wave, then the reference's exact Cramer/determinant test (default_schema.hpp:57-78) in
+//    the reference's operation order for surviving lanes, its three IEEE divisions performed only
+//    where a 1-ulp reciprocal cannot decide.  All of these can only produce false positives, so
+//    results are identical to the reference's linear walk (ties broken by file order).
+//  * shadow rays stop at the first occluder when no material is transparent.
 //  * the duplicated primary cast (kernel.hpp:52 + shading.hpp:123) is done once.
 //
-// Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE correctly
-// rounded on gfx950, so every geometric quantity (depth, hit, normal, which object
-// is hit) is bit-identical to the host-compiled reference.  pow() is evaluated in
-// f64 and rounded once (≤1 ulp from glibc powf), it only feeds the specular colour.
-// Texture coordinates (atan2/asin, uv_for) are never produced: the only material
-// type ignores them (default_schema.hpp:326-340).
+// Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE correctly rounded on gfx950,
+// so every geometric quantity (depth, hit, normal, which object is hit) is bit-identical to the
+// host-compiled reference.  The specular pow() is exp2(e*log2(x)) in f32 by default (<= 1e-6
+// relative where it matters) or f64 pow rounded once (CTR_VAR_EXACT_POW, bit-identical to glibc
+// powf on every tested pixel); it only feeds the colour.  Texture coordinates (atan2/asin, uv_for)
+// are never produced: the only material type ignores them (default_schema.hpp:326-340).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -60,18 +64,6 @@ namespace {
 #ifndef CTR_WAVES_PER_WG
 #define CTR_WAVES_PER_WG 1
 #endif
-#ifndef CTR_LEAF_UNROLL
-#define CTR_LEAF_UNROLL 1
-#endif
-#ifndef CTR_WHOLE_OBJ
-#define CTR_WHOLE_OBJ 0
-#endif
-#ifndef CTR_PREFETCH
-#define CTR_PREFETCH 0
-#endif
-#ifndef CTR_TILE_STRIDE
-#define CTR_TILE_STRIDE 0
-#endif
 #ifndef CTR_MIN_WAVES_EU
 #define CTR_MIN_WAVES_EU 4
 #endif
@@ -79,7 +71,6 @@ constexpr int TW = CTR_TW, TH = CTR_TH;  // pixel tile of one wave (TW*TH == 64)
 static_assert(TW * TH == 64, "one wave = one TW x TH tile");
 constexpr int WAVES_PER_WG = CTR_WAVES_PER_WG;
 constexpr int WG_THREADS = 64 * WAVES_PER_WG;
-constexpr int MAX_DEPTH = CTR_MAX_BOUNCES + 1;
 
 struct V3 { float x, y, z; };
 
@@ -114,18 +105,6 @@ __device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a
 // (every push decrements it): bl = bounces - depth.
 enum { F_R = 0, F_G, F_B, F_REFL, F_TRANSL, F_STAGE, F_PX, F_PY, F_PZ, F_DX, F_DY, F_DZ };
 
-// copy one 64-byte record out of the constant address space (16 dwords -> SGPRs when uniform)
-template <class T>
-__device__ __forceinline__ T ldc(const CADDR T *p) {
-  static_assert(sizeof(T) == 64, "64-byte records only");
-  T r;
-  const CADDR uint32_t *src = (const CADDR uint32_t *)p;
-  uint32_t *dst = (uint32_t *)&r;
-#pragma unroll
-  for (int q = 0; q < 16; q++) dst[q] = src[q];
-  return r;
-}
-
 struct KArgs {
   const CADDR DObj *objs;      // every object in scene order (hit records)
   const CADDR DObj *oloop;     // non-plane objects (generic loop)
@@ -143,7 +122,6 @@ struct KArgs {
   uint32_t w, h;
   uint32_t first_frame, n_frames;
   uint64_t frame_stride_px;    // pixels between consecutive frames in the output buffers
-  uint32_t tile_mul;           // multiplier coprime to the tiles per frame (strided tile order)
   DRows rows;
   float fudge;
   int bounces;
@@ -196,13 +174,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   if (wave >= tiles_frame * A.n_frames) return;  // whole wave exits together
   // batch of frames (a camera path): frame-major waves, one camera per frame (wave-uniform)
   const uint32_t frame = wave / tiles_frame;
-#if CTR_TILE_STRIDE
-  // visit the tiles of a frame in a strided order so that costly neighbouring tiles (the mesh)
-  // are not all resident at the same time
-  const uint32_t tile = (uint32_t)(((uint64_t)(wave - frame * tiles_frame) * A.tile_mul) % tiles_frame);
-#else
   const uint32_t tile = wave - frame * tiles_frame;
-#endif
   const CADDR DCam &cam = A.cams[A.first_frame + frame];
   const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
   const uint32_t x_id = tx * TW + (lane % TW);
@@ -516,9 +488,6 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           };
           auto leaf = [&](uint32_t desc, mask_t lanes) {
             const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
-#if CTR_LEAF_UNROLL > 1
-#pragma unroll CTR_LEAF_UNROLL
-#endif
             for (uint32_t k = 0; k < n_l; ++k) {
               if (VMEM) {
                 uint32_t iv = first + k;
@@ -707,11 +676,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         done_shadow = true;
       }
       if (done_shadow) {
-#ifdef ABL_SHADE
-        if (false) {
-#else
         if (shadow_fac < 1.0f) {
-#endif
           // shading.hpp:86-95
           const CADDR DMat &M = A.mats[mat_i];
           const CADDR DLight &Lg = A.lights[li];
@@ -931,15 +896,6 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   const size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
   const uint32_t tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
   const uint64_t waves = (uint64_t)tiles_x * tiles_y * L.n_frames;
-  {
-    // a multiplier near tiles/golden-ratio, coprime to the tile count
-    const uint32_t n = tiles_x * tiles_y;
-    uint32_t m = (uint32_t)(n * 0.6180339887) | 1u;
-    auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
-    while (n > 1 && gcd(m, n) != 1) m += 2;
-    A.tile_mul = n > 1 ? m % n : 0;
-    if (n > 1 && A.tile_mul == 0) A.tile_mul = 1;
-  }
   if (waves > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
   if (waves == 0) return 0;
   const uint32_t grid = (uint32_t)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
