@@ -55,11 +55,11 @@ def parse_args():
 
 def cpu_baseline(ca, host_scene, bounces, div):
     """Bounded CPU sample: every `div`-th 8-row block of the same frame, all host threads."""
-    from cutrace_amd import _lib
+    import oracle  # the checker libraries: this leg is the only place bench.py touches them
     w, h = host_scene.size
     threads = min(os.cpu_count() or 1, 64)
-    use_ref = _lib.ref_lib() is not None
-    fn = ca.ref_render if use_ref else ca.oracle_render
+    use_ref = oracle.ref_lib() is not None
+    fn = oracle.ref_render if use_ref else oracle.oracle_render
     if div <= 0:
         # aim at ~10-30 s: ~0.14 Mrays/s per thread measured for this workload
         est_full = 64.3e6 * (w * h / 2073600.0) / (0.14e6 * threads)

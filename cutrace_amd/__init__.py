@@ -118,36 +118,6 @@ def rows_count(h, rows):
     return int(_lib.host_lib().ctr_rows_count(C.byref(r), h))
 
 
-def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids):
-    w, h = scene.size
-    r = make_rows(h, rows)
-    n = rows_count(h, rows)
-    depth = np.empty((n, w), np.float32)
-    color = np.empty((n, w, 3), np.float32)
-    normal = np.empty((n, w, 3), np.float32)
-    hit = np.empty((n, w), np.int64) if want_hit_ids else None
-    counters = (C.c_uint64 * 2)()
-    st = fn(scene.desc, C.c_float(fudge), bounces, C.byref(r), threads, depth.ctypes.data, color.ctypes.data,
-            normal.ctypes.data, hit.ctypes.data if hit is not None else None, counters)
-    if st:
-        raise RuntimeError(f"cpu render failed: {st}")
-    return dict(depth=depth, color=color, normal=normal, hit_id=hit, ray_count=int(counters[0]),
-                alg_bytes=int(counters[1]))
-
-
-def oracle_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
-    """CPU restatement (oracle/ctr_oracle.c).  CHECKER ONLY — tests, smoke(), bench cpu_baseline."""
-    return _cpu_render(_lib.oracle_lib().orc_render, scene, fudge, bounces, rows, threads, hit_ids)
-
-
-def ref_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
-    """The reference's own headers compiled for the host (oracle/_ref).  CHECKER ONLY."""
-    L = _lib.ref_lib()
-    if L is None:
-        raise RuntimeError("oracle/_ref/libcutrace_ref.so not built (needs /root/reference)")
-    return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)
-
-
 class DeviceScene:
     """A scene uploaded to one GPU through the C-ABI (ctr_scene_create)."""
 

@@ -77,8 +77,6 @@ HIP_SYMBOLS = [
 
 _host = None
 _hip = None
-_oracle = None
-_ref = None
 
 
 def host_lib():
@@ -141,40 +139,3 @@ def hip_lib():
                                             C.POINTER(C.c_uint64)]
         _hip = L
     return _hip
-
-
-def _render_sig(fn):
-    fn.argtypes = [C.POINTER(SceneDesc), C.c_float, C.c_int, C.POINTER(Rows), C.c_int, C.c_void_p, C.c_void_p,
-                   C.c_void_p, C.c_void_p, C.c_void_p]
-    fn.restype = C.c_int
-
-
-def oracle_lib():
-    """CPU restatement (oracle/ctr_oracle.c). Checker only: tests, smoke(), bench cpu_baseline."""
-    global _oracle
-    if _oracle is None:
-        path = os.path.join(ROOT, "oracle", "libctr_oracle.so")
-        if not os.path.exists(path):
-            raise RuntimeError(f"{path} missing: run `make -C oracle oracle`")
-        L = C.CDLL(path)
-        _render_sig(L.orc_render)
-        L.orc_look_at.argtypes = [C.POINTER(Camera), Vec3, Vec3, Vec3]
-        L.orc_quantise_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
-        L.orc_quantise_normal.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
-        L.orc_quantise_color.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
-        _oracle = L
-    return _oracle
-
-
-def ref_lib():
-    """The reference's own headers compiled for the host (oracle/_ref). None if not built."""
-    global _ref
-    if _ref is None:
-        path = os.path.join(ROOT, "oracle", "_ref", "libcutrace_ref.so")
-        if not os.path.exists(path):
-            return None
-        L = C.CDLL(path)
-        _render_sig(L.ref_render)
-        L.ref_look_at.argtypes = [C.POINTER(Camera), Vec3, Vec3, Vec3]
-        _ref = L
-    return _ref

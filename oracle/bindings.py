@@ -1,0 +1,79 @@
+"""ctypes bindings of oracle/libctr_oracle.so (plain-C restatement) and oracle/_ref/libcutrace_ref.so
+(the reference's own headers built for the host).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from cutrace_amd import _lib, make_rows, rows_count  # the ABI structs only; never the other way round
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_oracle = None
+_ref = None
+
+
+def _render_sig(fn):
+    fn.argtypes = [C.POINTER(_lib.SceneDesc), C.c_float, C.c_int, C.POINTER(_lib.Rows), C.c_int, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(HERE, "libctr_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle oracle`")
+        L = C.CDLL(path)
+        _render_sig(L.orc_render)
+        L.orc_look_at.argtypes = [C.POINTER(_lib.Camera), _lib.Vec3, _lib.Vec3, _lib.Vec3]
+        L.orc_quantise_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
+        L.orc_quantise_normal.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_quantise_color.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_trace_pixel.argtypes = [C.POINTER(_lib.SceneDesc), C.c_uint64, C.c_uint64, C.c_float, C.c_int]
+        _oracle = L
+    return _oracle
+
+
+def ref_lib():
+    """None when oracle/_ref has not been built (it needs /root/reference at build time)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(HERE, "_ref", "libcutrace_ref.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        _render_sig(L.ref_render)
+        L.ref_look_at.argtypes = [C.POINTER(_lib.Camera), _lib.Vec3, _lib.Vec3, _lib.Vec3]
+        _ref = L
+    return _ref
+
+
+def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids):
+    w, h = scene.size
+    r = make_rows(h, rows)
+    n = rows_count(h, rows)
+    depth = np.empty((n, w), np.float32)
+    color = np.empty((n, w, 3), np.float32)
+    normal = np.empty((n, w, 3), np.float32)
+    hit = np.empty((n, w), np.int64) if want_hit_ids else None
+    counters = (C.c_uint64 * 2)()
+    st = fn(scene.desc, C.c_float(fudge), bounces, C.byref(r), threads, depth.ctypes.data, color.ctypes.data,
+            normal.ctypes.data, hit.ctypes.data if hit is not None else None, counters)
+    if st:
+        raise RuntimeError(f"cpu render failed: {st}")
+    return dict(depth=depth, color=color, normal=normal, hit_id=hit, ray_count=int(counters[0]),
+                alg_bytes=int(counters[1]))
+
+
+def oracle_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
+    """CPU restatement (oracle/ctr_oracle.c)."""
+    return _cpu_render(oracle_lib().orc_render, scene, fudge, bounces, rows, threads, hit_ids)
+
+
+def ref_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
+    """The reference's own headers compiled for the host (oracle/_ref)."""
+    L = ref_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libcutrace_ref.so not built (needs /root/reference)")
+    return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)

@@ -5,7 +5,8 @@ import cutrace_amd as ca
 from cutrace_amd import scenes
 p = scenes.make_mirror_deep(tempfile.mkdtemp(), width=160, height=90)
 s = ca.HostScene.load(p)
-o = ca.oracle_render(s, bounces=8, threads=16)
+import oracle
+o = oracle.oracle_render(s, bounces=8, threads=16)
 ds = ca.DeviceScene(s)
 for name, v in (("auto", 0), ("no_bvh", 8), ("no_anyhit", 4), ("no_prefilter", 2), ("exactpow", 32), ("none", 2 | 4 | 8 | 32)):
     ds.set_variant(v)

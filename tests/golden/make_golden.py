@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import cutrace_amd as ca  # noqa: E402
+import oracle  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 THREADS = os.cpu_count() or 8
@@ -50,7 +51,7 @@ def main():
         s = ca.HostScene.load(f"scene/{name}.json")
         assert s.ok
         s.set_size(w, h)
-        r = ca.ref_render(s, bounces=b, threads=THREADS)
+        r = oracle.ref_render(s, bounces=b, threads=THREADS)
         path = os.path.join(OUT, f"small_{name}_{w}x{h}_b{b}.npz")
         np.savez_compressed(path, depth=r["depth"], color=r["color"], normal=r["normal"], hit_id=r["hit_id"].astype(np.int32),
                             **sums(r))
@@ -61,7 +62,7 @@ def main():
     for name, w, h, b in FULL:
         s = ca.HostScene.load(f"scene/{name}.json")
         assert s.ok and s.size == (w, h)
-        r = ca.ref_render(s, bounces=b, threads=THREADS)
+        r = oracle.ref_render(s, bounces=b, threads=THREADS)
         idx = np.sort(rng.choice(w * h, 4096, replace=False)).astype(np.int64)
         path = os.path.join(OUT, f"full_{name}_{w}x{h}_b{b}.npz")
         np.savez_compressed(path, sample_idx=idx, depth=r["depth"].reshape(-1)[idx], color=r["color"].reshape(-1, 3)[idx],

@@ -8,6 +8,8 @@ import subprocess
 import numpy as np
 import pytest
 
+import oracle
+
 from tests.util import assert_parity, same_bits
 
 pytestmark = pytest.mark.gpu
@@ -24,7 +26,7 @@ def test_c2_dense_bunny_64k_triangles(ca, gen_dir):
     path = scenes.make_dense_bunny(gen_dir, rounds=3, width=64, height=36)
     s = ca.HostScene.load(path)
     assert s.ok and s.desc.contents.n_triangles == 64000
-    o = ca.oracle_render(s, bounces=5, threads=NT)
+    o = oracle.oracle_render(s, bounces=5, threads=NT)
     ds = ca.DeviceScene(s)
     r = ds.render(bounces=5)
     assert_parity(r, o, what="dense bunny 64x36")
@@ -45,7 +47,7 @@ def test_c3_deep_mirror_depth_8(ca, gen_dir):
     path = scenes.make_mirror_deep(gen_dir, width=160, height=90)
     s = ca.HostScene.load(path)
     assert s.ok
-    o = ca.oracle_render(s, bounces=8, threads=NT)
+    o = oracle.oracle_render(s, bounces=8, threads=NT)
     r = ca.DeviceScene(s).render(bounces=8)
     assert_parity(r, o, what="mirror deep 160x90 b8")
     assert r["ray_count"] == o["ray_count"]
@@ -60,7 +62,7 @@ def test_c4_bunny_grid(ca, gen_dir):
     assert s.ok
     d = s.desc.contents
     assert d.n_objects == 21 and d.n_triangles == 16000
-    o = ca.oracle_render(s, bounces=5, threads=NT)
+    o = oracle.oracle_render(s, bounces=5, threads=NT)
     ds = ca.DeviceScene(s)
     r = ds.render(bounces=5)
     assert_parity(r, o, what="bunny grid 96x96")
@@ -94,7 +96,7 @@ def test_axis_parallel_rays_through_meshes(ca):
     }
     s = ca.HostScene.parse(json.dumps(sc))
     assert s.ok
-    o = ca.oracle_render(s, bounces=4, threads=NT)
+    o = oracle.oracle_render(s, bounces=4, threads=NT)
     ds = ca.DeviceScene(s)
     for variant in (ca.VAR_EXACT_POW, ca.VAR_EXACT_POW | ca.VAR_NO_CLUSTER, ca.VAR_EXACT_POW | ca.VAR_VMEM, 0):
         ds.set_variant(variant)
@@ -118,10 +120,10 @@ def test_cli_drop_in(ca, tmp_path):
     assert "Render time was " in p.stdout and " ms; kernel time with setup/teardown was " in p.stdout
     s = ca.HostScene.load("scene/bunny.json")
     s.set_size(160, 90)
-    o = ca.oracle_render(s, bounces=5, threads=NT)
+    o = oracle.oracle_render(s, bounces=5, threads=NT)
     q = np.zeros((90, 160, 3), np.uint8)
     from cutrace_amd import _lib
-    _lib.oracle_lib().orc_quantise_color(o["color"].ctypes.data, 160 * 90, q.ctypes.data)
+    oracle.oracle_lib().orc_quantise_color(o["color"].ctypes.data, 160 * 90, q.ctypes.data)
     for name in ("frame.jpg", "depth_map.jpg", "normal_map.jpg"):
         im = Image.open(tmp_path / name)
         assert im.size == (160, 90)

@@ -11,6 +11,8 @@ import os
 import numpy as np
 import pytest
 
+import oracle
+
 from tests.conftest import load_scene
 from tests.test_oracle_golden import GOLD, parse
 from tests.util import assert_parity, same_bits
@@ -50,7 +52,7 @@ VARIANTS = [0, 32, 2, 4, 8, 4 | 8, 2 | 4 | 8 | 32]  # AUTO, EXACT_POW, NO_PREFIL
 @pytest.mark.parametrize("name,w,h,b", [("bunny", 160, 90, 5), ("mirror", 160, 90, 8), ("sphere_plane", 160, 90, 5)])
 def test_gpu_matches_oracle_all_variants(gpu, name, w, h, b, variant):
     s = load_scene(gpu, name, w, h)
-    o = gpu.oracle_render(s, bounces=b, threads=os.cpu_count() or 4)
+    o = oracle.oracle_render(s, bounces=b, threads=os.cpu_count() or 4)
     ds = gpu.DeviceScene(s)
     ds.set_variant(variant)
     r = ds.render(bounces=b)
@@ -128,7 +130,7 @@ def test_edge_cases(gpu):
                        {"type": "triangle", "p1": [-3, -3, 1], "p2": [3, -3, 1], "p3": [0, 3, 1], "material": 0}]
     s = gpu.HostScene.parse(json.dumps(base))
     for b in (0, 1, 3, 15):
-        o = gpu.oracle_render(s, bounces=b)
+        o = oracle.oracle_render(s, bounces=b)
         r = gpu.DeviceScene(s).render(bounces=b)
         assert_parity(r, o, what=f"no-lights bounces={b}")
         assert r["ray_count"] == o["ray_count"]
@@ -139,7 +141,7 @@ def test_deep_recursion_scene(gpu):
     every path really reaches depth 8 (divergent secondary rays)."""
     s = load_scene(gpu, "mirror", 128, 72)
     s.set_material(1, reflexivity=0.5)
-    o = gpu.oracle_render(s, bounces=8, threads=os.cpu_count() or 4)
+    o = oracle.oracle_render(s, bounces=8, threads=os.cpu_count() or 4)
     r = gpu.DeviceScene(s).render(bounces=8)
     assert_parity(r, o, what="mirror deep b8")
     assert r["ray_count"] == o["ray_count"]
@@ -225,3 +227,52 @@ def test_bad_arguments_fail_loudly(gpu):
         ds.render(bounces=99)
     with pytest.raises(RuntimeError):
         ds.render(rows=(3, 20, 8, 0, 2))  # row_begin not block-aligned with n_parts > 1
+
+
+def _random_scene(seed, w=72, h=48):
+    """Seeded random scene mixing every primitive, light and material feature (incl. reflect +
+    transparency on the same material, coincident planes, a mesh and stand-alone triangles)."""
+    import json
+    rng = np.random.RandomState(seed)
+
+    def v(lo, hi):
+        return [float(x) for x in rng.uniform(lo, hi, 3)]
+
+    mats = []
+    for _ in range(int(rng.randint(2, 6))):
+        mats.append({"type": "solid", "color": v(0.05, 1.0), "specular": float(rng.uniform(0, 1)),
+                     "reflect": float(rng.choice([0.0, 0.0, 0.3, 0.9])), "phong": float(rng.choice([0.0, 1.0, 20.0, 300.0])),
+                     "transparency": float(rng.choice([0.0, 0.0, 0.0, 0.5]))})
+    nm = len(mats)
+    objs = []
+    for _ in range(int(rng.randint(1, 5))):
+        objs.append({"type": "sphere", "center": v(-1.5, 1.5), "radius": float(rng.uniform(0.2, 0.8)), "material": int(rng.randint(nm))})
+    for _ in range(int(rng.randint(1, 4))):
+        objs.append({"type": "triangle", "p1": v(-2, 2), "p2": v(-2, 2), "p3": v(-2, 2), "material": int(rng.randint(nm))})
+    floor = {"type": "plane", "point": [0, -1.2, 0], "normal": [0, 1, 0], "material": int(rng.randint(nm))}
+    objs.append(floor)
+    if rng.rand() < 0.5:
+        objs.append(dict(floor, material=int(rng.randint(nm))))  # coincident plane: exact tie on t
+    objs.append({"type": "plane", "point": [0, 0, -3], "normal": [0, 0, 1], "material": int(rng.randint(nm))})
+    if rng.rand() < 0.7:
+        objs.insert(int(rng.randint(len(objs) + 1)), {"type": "mesh", "file": "scene/skull.stl", "material": int(rng.randint(nm))})
+    lights = [{"type": "sun", "direction": v(-1, 1), "color": v(0.2, 1)}]
+    for _ in range(int(rng.randint(0, 3))):
+        lights.append({"type": "point", "point": v(-3, 3), "color": v(0.2, 1)})
+    cam = {"eye": [float(rng.uniform(-1, 3)), float(rng.uniform(-0.5, 2)), 4.0], "up": [0, 1, 0], "look": v(-0.5, 0.5),
+           "near_plane": 0.1, "far_plane": 100.0, "width": w, "height": h, "ambient": float(rng.uniform(0, 0.3))}
+    return json.dumps({"camera": cam, "lights": lights, "materials": mats, "objects": objs})
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_seeded_random_scenes(gpu, seed):
+    s = gpu.HostScene.parse(_random_scene(seed))
+    assert s.ok
+    b = [0, 2, 3, 5][seed % 4]
+    o = oracle.oracle_render(s, bounces=b, threads=os.cpu_count() or 4)
+    ds = gpu.DeviceScene(s)
+    for variant in (gpu.VAR_AUTO, gpu.VAR_EXACT_POW | gpu.VAR_NO_CLUSTER | gpu.VAR_NO_PREFILTER | gpu.VAR_NO_ANYHIT):
+        ds.set_variant(variant)
+        r = ds.render(bounces=b)
+        assert_parity(r, o, what=f"random scene seed {seed} variant {variant}")
+        assert r["ray_count"] == o["ray_count"]

@@ -7,6 +7,8 @@ import struct
 
 import numpy as np
 
+import oracle
+
 from cutrace_amd import _lib
 from tests.conftest import load_scene
 
@@ -116,7 +118,7 @@ def test_quantisation_matches_oracle(ca):
     normal = rng.normal(size=(n, 3)).astype(np.float32)
     normal[::13] = 0
     color = rng.uniform(-0.2, 1.3, (n, 3)).astype(np.float32)
-    H, O = _lib.host_lib(), _lib.oracle_lib()
+    H, O = _lib.host_lib(), oracle.oracle_lib()
     for fn_h, fn_o, src, extra in (
         (H.ctr_quantise_depth, O.orc_quantise_depth, depth, (C.c_float(9.0),)),
         (H.ctr_quantise_normal, O.orc_quantise_normal, normal, ()),

@@ -11,6 +11,8 @@ import re
 import numpy as np
 import pytest
 
+import oracle
+
 from tests.conftest import load_scene
 from tests.util import same_bits
 
@@ -32,7 +34,7 @@ def test_oracle_matches_golden_bit_for_bit(ca, path):
     name, w, h, b = parse(path)
     g = np.load(path)
     s = load_scene(ca, name, w, h)
-    r = ca.oracle_render(s, bounces=b, threads=4)
+    r = oracle.oracle_render(s, bounces=b, threads=4)
     assert same_bits(r["depth"], g["depth"])
     assert same_bits(r["normal"], g["normal"])
     assert same_bits(r["color"], g["color"])
@@ -43,13 +45,13 @@ def test_oracle_matches_golden_bit_for_bit(ca, path):
 def test_survey_known_answers(ca):
     """Numbers SURVEY.md §8(c) recorded from the host-compiled reference."""
     s = load_scene(ca, "triangle")  # 20x20 as shipped
-    r = ca.oracle_render(s, bounces=5)
+    r = oracle.oracle_render(s, bounces=5)
     fin = np.isfinite(r["depth"])
     assert int(fin.sum()) == 38
     assert np.allclose(r["color"].astype(np.float64).reshape(-1, 3).sum(0), [0.266, 0.076, 0.266], atol=1e-6)
     assert abs(float(r["depth"][fin].astype(np.float64).sum()) - 192.460781) < 1e-5
     s = load_scene(ca, "triangle", 128, 128)
-    r = ca.oracle_render(s, bounces=5)
+    r = oracle.oracle_render(s, bounces=5)
     assert int(np.isfinite(r["depth"]).sum()) == 1301
     assert r["ray_count"] == 34069
 
@@ -61,7 +63,7 @@ def test_full_resolution_samples_sphere_plane(ca):
         pytest.skip("full-resolution golden not generated")
     g = np.load(path)
     s = load_scene(ca, "sphere_plane")
-    r = ca.oracle_render(s, bounces=5, threads=os.cpu_count() or 4)
+    r = oracle.oracle_render(s, bounces=5, threads=os.cpu_count() or 4)
     idx = g["sample_idx"]
     assert same_bits(r["depth"].reshape(-1)[idx], g["depth"])
     assert same_bits(r["color"].reshape(-1, 3)[idx], g["color"])
@@ -77,11 +79,11 @@ REF_CASES = [("triangle", 20, 20, 5), ("sphere_plane", 64, 36, 5), ("sphere_plan
 @pytest.mark.parametrize("name,w,h,b", REF_CASES)
 def test_oracle_matches_live_reference_build(ca, name, w, h, b):
     from cutrace_amd import _lib
-    if _lib.ref_lib() is None:
+    if oracle.ref_lib() is None:
         pytest.skip("oracle/_ref not built here (needs /root/reference)")
     s = load_scene(ca, name, w, h)
-    o = ca.oracle_render(s, bounces=b, threads=4)
-    r = ca.ref_render(s, bounces=b, threads=4)
+    o = oracle.oracle_render(s, bounces=b, threads=4)
+    r = oracle.ref_render(s, bounces=b, threads=4)
     for k in ("depth", "normal", "color"):
         assert same_bits(o[k], r[k]), k
     assert np.array_equal(o["hit_id"], r["hit_id"])
@@ -91,12 +93,12 @@ def test_oracle_matches_live_reference_build(ca, name, w, h, b):
 def test_row_selection_matches_full_frame(ca):
     """Interleaved row blocks (the multi-GPU tiling) reproduce the full frame exactly."""
     s = load_scene(ca, "sphere_plane", 64, 40)
-    full = ca.oracle_render(s, bounces=3, threads=4)
+    full = oracle.oracle_render(s, bounces=3, threads=4)
     n_parts, br = 3, 8
     total = 0
     for part in range(n_parts):
         rows = (0, 40, br, part, n_parts)
-        r = ca.oracle_render(s, bounces=3, rows=rows, threads=2)
+        r = oracle.oracle_render(s, bounces=3, rows=rows, threads=2)
         ys = [y for y in range(40) if (y // br) % n_parts == part]
         assert r["depth"].shape[0] == len(ys) == ca.rows_count(40, rows)
         assert same_bits(r["color"], full["color"][ys])
@@ -112,10 +114,10 @@ def test_look_at_matches(ca):
     eye, up, look = _lib.Vec3(1, 0, 2), _lib.Vec3(0, 1, 0), _lib.Vec3(-0.92388, 0, -0.38268)
     a, b = _lib.Camera(), _lib.Camera()
     _lib.host_lib().ctr_camera_look_at(C.byref(a), eye, up, look)
-    _lib.oracle_lib().orc_look_at(C.byref(b), eye, up, look)
+    oracle.oracle_lib().orc_look_at(C.byref(b), eye, up, look)
     for f in ("pos", "up", "forward", "right"):
         assert getattr(a, f).tup() == getattr(b, f).tup()
-    R = _lib.ref_lib()
+    R = oracle.ref_lib()
     if R is not None:
         c = _lib.Camera()
         R.ref_look_at(C.byref(c), eye, up, look)

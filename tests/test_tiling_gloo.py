@@ -7,6 +7,8 @@ import sys
 
 import numpy as np
 import pytest
+
+import oracle
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -37,7 +39,7 @@ def _worker(rank, world, port, w, h, frames, steps, out_path):
         slot = step % tiler.slots
         tiler.begin(slot)
         for f in range(frames):
-            r = ca.oracle_render(s, bounces=2 + f, rows=tiler.frame_rows(f), threads=2)  # frames differ by bounces
+            r = oracle.oracle_render(s, bounces=2 + f, rows=tiler.frame_rows(f), threads=2)  # frames differ by bounces
             d, c, n = tiler.views(slot, f)
             d.copy_(torch.from_numpy(r["depth"]).reshape(-1))
             c.copy_(torch.from_numpy(r["color"]).reshape(-1))
@@ -64,7 +66,7 @@ def test_gather_reassembles_frames(ca, tmp_path, world, h):
     s.set_size(w, h)
     rays = 0
     for f in range(frames):
-        full = ca.oracle_render(s, bounces=2 + f, threads=4)
+        full = oracle.oracle_render(s, bounces=2 + f, threads=4)
         rays += full["ray_count"]
         assert np.array_equal(got["depth"][f].view(np.uint32), full["depth"].view(np.uint32))
         assert np.array_equal(got["color"][f].view(np.uint32), full["color"].view(np.uint32))
