@@ -218,10 +218,10 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   float *const stk = lds_stack + (size_t)wave_in_wg * A.frames * A.nf * 64 + lane;
 #define STK(frame, field) stk[((frame) * A.nf + (field)) * 64]
   V3 in_d = rd;             // direction of the radiance ray being shaded ("incoming"); its start is `ro` until the hit
-  V3 hit = mk(0, 0, 0), nn = mk(0, 0, 0), pos = mk(0, 0, 0);
+  V3 nn = mk(0, 0, 0), pos = mk(0, 0, 0);  // (the hit point itself lives in `ro` from the hit on: it is
+                                           //  the origin of every shadow ray of that hit)
   V3 in_dn = mk(0, 0, 0);   // incoming->dir.normalized() (shading.hpp:90,131; default_schema.hpp:245)
   V3 fin = mk(0, 0, 0);     // phong accumulator ("final")
-  V3 nd = mk(0, 0, 0);      // normalized direction to the current light
   float light_dist = 0.f, intensity = 0.f;
   uint32_t mat_i = 0, li = 0;
   V3 out_rgb = mk(0, 0, 0);
@@ -628,13 +628,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         const uint32_t ht = H.type;
         if (ht == CTR_OBJ_SPHERE) {
           // default_schema.hpp:245-246: hit uses the NORMALIZED direction
-          hit = vadd(ro, vscale(in_dn, best));
+          const V3 hit = vadd(ro, vscale(in_dn, best));
           normal = vnormalized(vsub(hit, mk(H.f[0], H.f[1], H.f[2])));
+          ro = hit;
         } else if (ht == CTR_OBJ_PLANE) {
-          hit = pos;
+          ro = pos;
           normal = mk(H.f[3], H.f[4], H.f[5]);
         } else {
-          hit = pos;
+          ro = pos;
           normal = mk(A.gnorm[4 * btri + 0], A.gnorm[4 * btri + 1], A.gnorm[4 * btri + 2]);
         }
       }
@@ -683,6 +684,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           const V3 diffuse = mk(M.cx, M.cy, M.cz);
           const V3 specular = vscale(diffuse, M.specular);  // default_schema.hpp:328
           const V3 color = mk(Lg.cx, Lg.cy, Lg.cz);
+          const V3 nd = rd;  // the shadow ray's direction IS the normalized direction to the light
           const float fd = smax(0.0f, vdot(nn, nd));
           const V3 ld = vmul(diffuse, color);
           const V3 hv = vnormalized(vadd(vscale(in_dn, -1.0f), nd));
@@ -713,14 +715,12 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           direction = vscale(mk(Lg.vx, Lg.vy, Lg.vz), -1.0f);
           distance = INFINITY;
         } else {                         // default_schema.hpp:305-308
-          const V3 diff = vsub(mk(Lg.vx, Lg.vy, Lg.vz), hit);
+          const V3 diff = vsub(mk(Lg.vx, Lg.vy, Lg.vz), ro);  // ro == *hit
           direction = vnormalized(diff);
           distance = vnorm(diff);
         }
-        nd = vnormalized(direction);
+        rd = vnormalized(direction);  // shadow ray {*hit, direction.normalized()}, shading.hpp:80
         light_dist = distance * vnorm(direction);
-        ro = hit;
-        rd = nd;
         intensity = 0.0f;
         min_t = (float)(0.0 + 1e-3);  // last_hit = 0
         mode = M_SHADOW;
