@@ -94,6 +94,9 @@ struct ctr_scene {
   int device = 0;
   DObj *d_objs = nullptr;
   DObj *d_oloop = nullptr;
+  DObj *d_meshes = nullptr;
+  uint32_t n_mesh = 0, tlas_root = BVH_LEAF_FLAG, tlas_begin = 0;
+  float tl_mn[3] = {0, 0, 0}, tl_mx[3] = {0, 0, 0};
   DPlane *d_planes = nullptr;
   uint32_t n_oloop = 0, n_planes = 0;
   DTri *d_tris = nullptr;
@@ -178,6 +181,11 @@ int make_rows(const ctr_scene *s, const ctr_rows *rin, DRows &R) {
 void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.objs = s->d_objs;
   L.oloop = s->d_oloop;
+  L.meshes = s->d_meshes;
+  L.n_mesh = s->n_mesh;
+  L.tlas_root = s->tlas_root;
+  L.tlas_begin = s->tlas_begin;
+  for (int q = 0; q < 3; q++) { L.tl_mn[q] = s->tl_mn[q]; L.tl_mx[q] = s->tl_mx[q]; }
   L.planes = s->d_planes;
   L.n_oloop = s->n_oloop;
   L.n_planes = s->n_planes;
@@ -333,11 +341,33 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         break;
     }
   }
-  std::vector<DObj> oloop;
+  std::vector<DObj> oloop, meshes_in, meshes;
   std::vector<DPlane> planes;
   for (const DObj &O : objs) {
     if (O.type == CTR_OBJ_PLANE) planes.push_back(DPlane{O.f[0], O.f[1], O.f[2], O.f[3], O.f[4], O.f[5], O.index, O.mat});
+    else if (O.type == CTR_OBJ_MESH) { if (O.tri_count) meshes_in.push_back(O); }  // an empty mesh is never hit
     else oloop.push_back(O);
+  }
+  // top-level BVH over the mesh boxes, one mesh per leaf (same node layout as the per-mesh trees)
+  uint32_t tlas_root = BVH_LEAF_FLAG, tlas_begin = (uint32_t)nodes.size();
+  float tl_mn[3] = {0, 0, 0}, tl_mx[3] = {0, 0, 0};
+  if (!meshes_in.empty()) {
+    std::vector<BvhInput> prims(meshes_in.size());
+    for (int a = 0; a < 3; a++) { tl_mn[a] = INFINITY; tl_mx[a] = -INFINITY; }
+    for (size_t k = 0; k < meshes_in.size(); k++) {
+      for (int a = 0; a < 3; a++) {
+        prims[k].mn[a] = meshes_in[k].f[a];
+        prims[k].mx[a] = meshes_in[k].f[3 + a];
+        prims[k].c[a] = 0.5f * (prims[k].mn[a] + prims[k].mx[a]);
+        tl_mn[a] = fminf(tl_mn[a], prims[k].mn[a]);
+        tl_mx[a] = fmaxf(tl_mx[a], prims[k].mx[a]);
+      }
+    }
+    std::vector<DNode> tnodes;
+    std::vector<uint32_t> order;
+    bvh_build(prims, 1, tnodes, order, tlas_root);
+    nodes.insert(nodes.end(), tnodes.begin(), tnodes.end());
+    for (uint32_t k : order) meshes.push_back(meshes_in[k]);
   }
   std::vector<DLight> lights(d->n_lights);
   for (uint64_t i = 0; i < d->n_lights; i++) {
@@ -375,9 +405,14 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   };
   hipError_t er;
   s->n_oloop = (uint32_t)oloop.size();
+  s->n_mesh = (uint32_t)meshes.size();
+  s->tlas_root = tlas_root;
+  s->tlas_begin = tlas_begin;
+  for (int q = 0; q < 3; q++) { s->tl_mn[q] = tl_mn[q]; s->tl_mx[q] = tl_mx[q]; }
   s->n_planes = (uint32_t)planes.size();
   if ((er = upload((void **)&s->d_objs, objs.data(), objs.size() * sizeof(DObj))) != hipSuccess ||
       (er = upload((void **)&s->d_oloop, oloop.data(), oloop.size() * sizeof(DObj))) != hipSuccess ||
+      (er = upload((void **)&s->d_meshes, meshes.data(), meshes.size() * sizeof(DObj))) != hipSuccess ||
       (er = upload((void **)&s->d_planes, planes.data(), planes.size() * sizeof(DPlane))) != hipSuccess ||
       (er = upload((void **)&s->d_tris, tris.data(), tris.size() * sizeof(DTri))) != hipSuccess ||
       (er = upload((void **)&s->d_nodes, nodes.data(), nodes.size() * sizeof(DNode))) != hipSuccess ||
@@ -423,7 +458,7 @@ int ctr_scene_set_cameras(ctr_scene *s, const ctr_camera *cams, uint32_t n) {
 void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
+  for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
                   (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters, (void *)s->d_shards})
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);

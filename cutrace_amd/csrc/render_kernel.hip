@@ -52,6 +52,7 @@
 #define INVB(m) __builtin_amdgcn_inverse_ballot_w64(m)   /* wave-uniform lane mask -> per-lane predicate */
 #define FCMP(a, b, pred) __builtin_amdgcn_fcmpf((a), (b), (pred))  /* v_cmp straight into a lane mask */
 enum { FC_OGT = 2, FC_OGE = 3, FC_OLT = 4, FC_OLE = 5 };          /* LLVM FCmp predicate numbers */
+#define TL_NONE 0x7FFFFFFFu                                        /* "no more top-level items" */
 
 namespace {
 
@@ -107,7 +108,10 @@ enum { F_R = 0, F_G, F_B, F_REFL, F_TRANSL, F_STAGE, F_PX, F_PY, F_PZ, F_DX, F_D
 
 struct KArgs {
   const CADDR DObj *objs;      // every object in scene order (hit records)
-  const CADDR DObj *oloop;     // non-plane objects (generic loop)
+  const CADDR DObj *oloop;     // spheres and stand-alone triangles (sequential loop)
+  const CADDR DObj *meshes;    // meshes with >= 1 triangle, in top-level-BVH leaf order
+  uint32_t n_mesh, tlas_root, tlas_begin;
+  float tl_mn[3], tl_mx[3];    // box of all meshes (margin of the top-level walk)
   const CADDR DPlane *planes;
   uint32_t n_oloop, n_planes;
   const CADDR DTri *tris;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       }
       if (ANYHIT) live = INVB(live_m);
     }
-    // ---- every other object, scene order ----
+    // ---- spheres and stand-alone triangles, scene order ----
     for (uint32_t oi = 0; oi < A.n_oloop; ++oi) {
       if (ANYHIT) {
         if (BALLOT(live) == 0ull) break;
@@ -302,276 +306,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       bool ok = false;
       float cand = INFINITY;
       int ctri = -1;
-      if (type == CTR_OBJ_MESH) {
-        // Everything in this branch works on 64-bit lane masks (v_cmp results kept in SGPRs and
-        // combined on the scalar unit) instead of per-lane booleans.
-        TSTAMP(t_mesh0);
-        const mask_t live_m = BALLOT(live);
-        // ---- mesh::bound_intersects, default_schema.hpp:99-114 ----
-        // The reference's slab test needs three IEEE divisions (1/dir) per ray.  With 1-ulp
-        // reciprocals every t is within 3 ulp of the exact one and tmin/tmax are 1-Lipschitz in
-        // the t's, so lanes whose tmin/tmax differ by more than dl = 2^-20 * max|t| are decided
-        // without them; only borderline lanes (or NaN/inf: axis-parallel rays) take the exact path.
-        mask_t bb_m;
-        {
-          const float a1x = (O.f[0] - ro.x) * ria.x, a2x = (O.f[3] - ro.x) * ria.x;
-          const float a1y = (O.f[1] - ro.y) * ria.y, a2y = (O.f[4] - ro.y) * ria.y;
-          const float a1z = (O.f[2] - ro.z) * ria.z, a2z = (O.f[5] - ro.z) * ria.z;
-          const float lo_a = fmaxf(fmaxf(fmaxf(fminf(a1x, a2x), fminf(a1y, a2y)), fminf(a1z, a2z)), 0.0f);
-          const float hi_a = fminf(fminf(fmaxf(a1x, a2x), fmaxf(a1y, a2y)), fmaxf(a1z, a2z));
-          const float tabs = fmaxf(fmaxf(fmaxf(fabsf(a1x), fabsf(a2x)), fmaxf(fabsf(a1y), fabsf(a2y))),
-                                   fmaxf(fabsf(a1z), fabsf(a2z)));
-          const float dl = tabs * 0x1p-20f;
-          const mask_t def_hit = FCMP(lo_a + dl, hi_a, FC_OLT);
-          const mask_t def_miss = FCMP(lo_a - dl, hi_a, FC_OGT);
-          // axis-parallel rays always take the exact path: the reference's inf/NaN min/max semantics
-          // (0 x inf when the origin sits exactly on a box face) are not what finite arithmetic gives
-          const mask_t border = live_m & (~(def_hit | def_miss) | FCMP(ria_big, 1e29f, FC_OGE));
-          bb_m = live_m & def_hit & ~border;
-          if (border != 0ull) {
-            if (!have_rinv) {  // wave-uniform: the exact reciprocals are computed at most once per cast
-              float ox = rd.x, oy = rd.y, oz = rd.z;
-              PIN3(ox, oy, oz);  // keeps the three IEEE divisions in this rarely-taken branch (no hoisting)
-              rinv = mk(1.0f / ox, 1.0f / oy, 1.0f / oz);  // default_schema.hpp:103
-              have_rinv = true;
-            }
-            float tmin = 0.0f, tmax = INFINITY;
-            float t1 = (O.f[0] - ro.x) * rinv.x, t2 = (O.f[3] - ro.x) * rinv.x;
-            tmin = smin(smax(t1, tmin), smax(t2, tmin));
-            tmax = smax(smin(t1, tmax), smin(t2, tmax));
-            t1 = (O.f[1] - ro.y) * rinv.y; t2 = (O.f[4] - ro.y) * rinv.y;
-            tmin = smin(smax(t1, tmin), smax(t2, tmin));
-            tmax = smax(smin(t1, tmax), smin(t2, tmax));
-            t1 = (O.f[2] - ro.z) * rinv.z; t2 = (O.f[5] - ro.z) * rinv.z;
-            tmin = smin(smax(t1, tmin), smax(t2, tmin));
-            tmax = smax(smin(t1, tmax), smin(t2, tmax));
-            bb_m |= border & FCMP(tmin, tmax, FC_OLE);
-          }
-        }
-        if (bb_m == 0ull) {  // no lane of this wave needs the mesh
-          TSTAMP(t_mesh_skip);
-          TACC(1, t_mesh0, t_mesh_skip);
-          continue;
-        }
-        const mask_t bb0_m = bb_m;
-        const uint32_t beg = O.tri_begin, cnt = O.tri_count;
-        if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
-        if (STATS) st[4]++;
-        // ---- mesh::intersect, default_schema.hpp:125-144: smallest valid t, FIRST triangle in
-        //      file order on ties (strict < over file order)  ==  lexicographic min of (t, orig) ----
-        float mt = INFINITY;
-        int mk_ = -1;
-        uint32_t morig = 0xFFFFFFFFu;
-        const bool anyhit_now = ANYHIT && shadow_cast;
-        // no triangle/node beyond `lim` can matter: the light for a deciding shadow ray, else the
-        // nearest hit so far (other objects, then this mesh)
-        float lim = anyhit_now ? light_dist : best;
-
-        // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
-        auto tri_test = [&](const auto &T, uint32_t tri_index, mask_t lanes_m) {
-          mask_t c_m = lanes_m;
-          if (STATS) st[2]++;
-          const float dx = T.px - ro.x, dy = T.py - ro.y, dz = T.pz - ro.z;
-          if (PREFILTER) {
-            // Conservative reject test.  Same quantities as the exact test
-            // (alpha = det[a b c], A1 = det[d b c], A2 = det[a d c]) evaluated with FMAs
-            // as triple products; every comparison carries a slack E that bounds both this
-            // evaluation's and the reference's rounding, and a
-            // NaN anywhere makes the lane a candidate.
-            const float alpha = __builtin_fmaf(rd.x, T.nx, __builtin_fmaf(rd.y, T.ny, rd.z * T.nz));
-            const float qx = __builtin_fmaf(dy, rd.z, -(dz * rd.y));
-            const float qy = __builtin_fmaf(dz, rd.x, -(dx * rd.z));
-            const float qz = __builtin_fmaf(dx, rd.y, -(dy * rd.x));
-            const float A1n = __builtin_fmaf(T.bx, qx, __builtin_fmaf(T.by, qy, T.bz * qz));  // = -A1
-            const float A2 = __builtin_fmaf(T.ax, qx, __builtin_fmaf(T.ay, qy, T.az * qz));
-            const uint32_t sgn = __float_as_uint(alpha) & 0x80000000u;
-            const float sA1 = __uint_as_float(__float_as_uint(A1n) ^ sgn ^ 0x80000000u);
-            const float sA2 = __uint_as_float(__float_as_uint(A2) ^ sgn);
-            const float absa = fabsf(alpha);
-            const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-            const float E = fmaxf(dmax * T.ke, T.ke2) * cmax;  // kappa * max(dmax,emax) * emax * cmax
-            const mask_t rej = FCMP(sA1, -E, FC_OLT) | FCMP(sA2, -E, FC_OLT) | FCMP(sA1 + sA2, absa + E, FC_OGT);
-            c_m = lanes_m & (~rej | FCMP(absa, E, FC_OLE));
-          }
-          if (c_m == 0ull) return;
-          if (STATS) st[3]++;
-          bool retire = false;  // any-hit: this lane found its occluder
-          if (INVB(c_m)) {
-            // ---- triangle::intersect, default_schema.hpp:57-78: the four determinants in the
-            //      reference's operation order ----
-            const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
-            const V3 d = mk(dx, dy, dz);
-            const float alpha = det3(a, b, rd);
-            const float A1 = det3(d, b, rd), A2 = det3(a, d, rd), A0 = det3(a, b, d);
-            // The three IEEE divisions (beta, gamma, t0) decide five comparisons and deliver t0.
-            // 1-ulp-reciprocal quotients are within 2^-21 relative of the exact ones, so with a
-            // 2^-18 margin (and an absolute floor for zero/denormal quotients) most lanes are
-            // decided without dividing; t0 itself is divided only where its value can matter.
-            const float r = __builtin_amdgcn_rcpf(alpha);
-            const float bq = A1 * r, gq = A2 * r, tq = A0 * r, sq = bq + gq;
-            const float eb = fabsf(bq) * 0x1p-18f + 1e-30f, eg = fabsf(gq) * 0x1p-18f + 1e-30f;
-            const float es = (fabsf(bq) + fabsf(gq) + 1.0f) * 0x1p-16f;
-            const float et = fabsf(tq) * 0x1p-18f + 1e-30f;
-            const bool def_rej = (bq < -eb) | (gq < -eg) | (sq > 1.0f + es) | (tq < min_t - et);
-            const bool def_acc = (bq > eb) & (gq > eg) & (sq < 1.0f - es) & (tq > min_t + et) & (fabsf(tq) < 1e37f);
-            bool acc = def_acc;
-            float t0 = tq;
-            bool exact_t = false;
-            if (!(def_rej | def_acc)) {
-              // borderline (or NaN/inf): the reference's own arithmetic
-              const float beta = A1 / alpha, gamma = A2 / alpha;
-              t0 = A0 / alpha;
-              exact_t = true;
-              acc = beta >= 0 && gamma >= 0 && beta + gamma <= 1 && __builtin_isfinite(t0) && min_t <= t0;
-            }
-            if (acc) {
-              if (anyhit_now) {
-                // A deciding shadow ray only asks whether some valid t lies in (min_t, light_dist).
-                // tq is within et of the exact t0 and already > min_t + et, so divide only when tq is
-                // within et of the light distance.
-                if (!exact_t && !(tq + et < light_dist) && !(tq - et >= light_dist)) t0 = A0 / alpha;
-                if (t0 > min_t && t0 < light_dist) {
-                  best = t0; bobj = (int)i;   // any value < light_dist: the handler only compares
-                  retire = true;
-                }
-              } else {
-                // the exact value of t0 matters only if it can beat or tie the nearest hit so far
-                if (!exact_t && !(tq - et > lim)) { t0 = A0 / alpha; exact_t = true; }
-                const uint32_t orig = T.orig;
-                if (exact_t && (t0 < mt || (t0 == mt && orig < morig))) {
-                  mt = t0; mk_ = (int)tri_index; morig = orig;
-                  lim = fminf(lim, mt);
-                }
-              }
-            }
-          }
-          if (ANYHIT) {
-            const mask_t rm = BALLOT(retire);
-            bb_m &= ~rm;
-          }
-        };
-
-        if (BVH) {
-          // Walk of the mesh's BVH by the whole wave together (bvh.h): an inner node holds BOTH
-          // children's boxes, so a child no lane touches is never loaded and leaves cost no node
-          // load.  Pending inner children wait on a wave-uniform stack kept in the lanes of ONE
-          // VGPR (v_writelane / v_readlane); the child on the near side of the split axis goes
-          // first.  The box test is conservative: boxes are widened by m = 2^-15 x (largest
-          // |coordinate difference| between the ray origin and the mesh), applied in t-space as a
-          // slack of 2*m*max|1/dir|; a NaN enters the box.
-          // The box test is conservative: every box is widened in WORLD space by
-          //   m = 2^-14 x (largest |coordinate difference| between the ray origin and the mesh box)
-          // per axis ((mn - m - o)/d and (mx + m - o)/d, folded into the two FMA constants below), far
-          // above the rounding of either this test or the reference's triangle test (DESIGN.md
-          // §bvh); a NaN (0 x inf for an axis-parallel ray) drops that axis' constraint.
-          const float gx = fmaxf(fabsf(O.f[0] - ro.x), fabsf(O.f[3] - ro.x));
-          const float gy = fmaxf(fabsf(O.f[1] - ro.y), fabsf(O.f[4] - ro.y));
-          const float gz = fmaxf(fabsf(O.f[2] - ro.z), fabsf(O.f[5] - ro.z));
-          const float mw = fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f;
-          const V3 ka = mk((ro.x + mw) * ria.x, (ro.y + mw) * ria.y, (ro.z + mw) * ria.z);  // for box minima
-          const V3 kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);  // for box maxima
-          const CADDR DNode *nodes = A.nodes + O.node_begin;
-          // direction signs of the first lane that needs the mesh decide the visiting order (speed only)
-          const uint32_t lead = (uint32_t)__builtin_ctzll(bb_m);
-          const uint32_t neg_bits = (__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31) |
-                                    ((__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31) << 1) |
-                                    ((__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31) << 2);
-          auto box_hits = [&](const auto &mn, const auto &mx) -> mask_t {
-            const float t1x = __builtin_fmaf(mn[0], ria.x, -ka.x), t2x = __builtin_fmaf(mx[0], ria.x, -kb.x);
-            const float t1y = __builtin_fmaf(mn[1], ria.y, -ka.y), t2y = __builtin_fmaf(mx[1], ria.y, -kb.y);
-            const float t1z = __builtin_fmaf(mn[2], ria.z, -ka.z), t2z = __builtin_fmaf(mx[2], ria.z, -kb.z);
-            const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-            const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-            // reject only on a definite miss (NaN compares false -> the box is entered)
-            const mask_t miss = FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, lim, FC_OGT);
-            return bb_m & ~miss;
-          };
-          auto leaf = [&](uint32_t desc, mask_t lanes) {
-            const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
-            for (uint32_t k = 0; k < n_l; ++k) {
-              if (VMEM) {
-                uint32_t iv = first + k;
-                HIDE_UNIFORM(iv);
-                const DTri Tv = A.tris_g[iv];
-                tri_test(Tv, first + k, lanes & bb_m);
-              } else {
-                tri_test(A.tris[first + k], first + k, lanes & bb_m);
-              }
-            }
-          };
-          uint32_t cur = O.bvh_root;
-          if (cur & BVH_LEAF_FLAG) {
-            leaf(cur, bb_m);  // the whole mesh fits one leaf
-          } else {
-            uint32_t stack_v = 0;  // lane k of this VGPR = stack slot k (depth <= BVH_MAX_DEPTH < 64)
-            uint32_t sp = 0;
-            for (;;) {
-              if (STATS) st[1]++;
-              mask_t hl, hr;
-              uint32_t n_left, n_right, n_axis;
-              if (VMEM) {
-                uint32_t cv = O.node_begin + cur;
-                HIDE_UNIFORM(cv);
-                const DNode Nv = A.nodes_g[cv];
-                hl = box_hits(Nv.lmn, Nv.lmx);
-                hr = box_hits(Nv.rmn, Nv.rmx);
-                n_left = __builtin_amdgcn_readfirstlane(Nv.left);
-                n_right = __builtin_amdgcn_readfirstlane(Nv.right);
-                n_axis = __builtin_amdgcn_readfirstlane(Nv.axis);
-              } else {
-                const CADDR DNode &N = nodes[cur];
-                hl = box_hits(N.lmn, N.lmx);
-                hr = box_hits(N.rmn, N.rmx);
-                n_left = N.left; n_right = N.right; n_axis = N.axis;
-              }
-              // near child first
-              const bool swap = ((neg_bits >> n_axis) & 1u) != 0u;
-              const uint32_t d0 = swap ? n_right : n_left, d1 = swap ? n_left : n_right;
-              const mask_t h0 = swap ? hr : hl, h1 = swap ? hl : hr;
-              uint32_t next = 0xFFFFFFFFu;
-              if (h0 != 0ull) {
-                if (d0 & BVH_LEAF_FLAG) leaf(d0, h0);
-                else next = d0;
-              }
-              if (h1 != 0ull && !(ANYHIT && bb_m == 0ull)) {
-                if (d1 & BVH_LEAF_FLAG) {
-                  // d0's leaf may have pulled `lim` in: lanes whose far box now lies beyond it drop out
-                  leaf(d1, h1);
-                } else if (next == 0xFFFFFFFFu) {
-                  next = d1;
-                } else {
-                  // v_writelane_b32: value and lane select are both wave-uniform; gfx9 allows one SGPR
-                  // operand per VALU instruction, so the lane select travels in M0
-                  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stack_v) : "s"(d1), "s"(sp) : "m0");
-                  sp++;
-                }
-              }
-              if (ANYHIT) {
-                if (bb_m == 0ull) break;
-              }
-              if (next == 0xFFFFFFFFu) {
-                if (sp == 0) break;
-                sp--;
-                next = __builtin_amdgcn_readlane(stack_v, sp);
-              }
-              cur = next;
-            }
-          }
-        } else {
-          for (uint32_t k = 0; k < cnt; ++k) {
-            tri_test(A.tris[beg + k], beg + k, bb_m);  // wave-uniform: one s_load_dwordx16
-            if (ANYHIT) {
-              if (bb_m == 0ull) break;
-            }
-          }
-        }
-        if (ANYHIT) live = live && !INVB(bb0_m & ~bb_m);  // lanes retired inside the mesh
-        ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
-        cand = mt;
-        ctri = mk_;
-        TSTAMP(t_mesh1);
-        TACC(1, t_mesh0, t_mesh1);
-      } else if (type == CTR_OBJ_SPHERE) {
+      if (type == CTR_OBJ_SPHERE) {
         // ---- sphere::intersect, default_schema.hpp:226-251 ----
         float sx_ = rd.x, sy_ = rd.y, sz_ = rd.z;
         PIN3(sx_, sy_, sz_);  // do not speculate the normalisation into scenes without spheres
@@ -607,6 +342,358 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       }
       if (ANYHIT) {
         if (shadow_cast && live && ok && cand > min_t && cand < light_dist) live = false;
+      }
+    }
+    // ---- meshes, reached through a top-level BVH over their boxes (bvh.h layout, one mesh per leaf)
+    //      so that a cast only looks at meshes some lane's ray can touch.  Visiting order does not
+    //      matter: the winner is the lexicographic minimum of (t, scene index). ----
+    if (A.n_mesh != 0u) {
+      uint32_t t_pend = A.tlas_root;           // next top-level item: inner node or mesh leaf
+      uint32_t t_stack_v = 0, t_sp = 0;        // wave-uniform stack in the lanes of one VGPR
+      for (;;) {
+        if (ANYHIT) {
+          if (BALLOT(live) == 0ull) break;
+        }
+        // descend the top-level tree to the next mesh leaf
+        if (!(t_pend & BVH_LEAF_FLAG)) {
+          const mask_t lv_m = BALLOT(live);
+          const float t_lim = anyhit_cast ? light_dist : best;
+          // conservative box test constants, as in the per-mesh walk below (world-space margin
+          // 2^-14 x G); recomputed per descent so that nothing stays live across the mesh code
+          const float gx = fmaxf(fabsf(A.tl_mn[0] - ro.x), fabsf(A.tl_mx[0] - ro.x));
+          const float gy = fmaxf(fabsf(A.tl_mn[1] - ro.y), fabsf(A.tl_mx[1] - ro.y));
+          const float gz = fmaxf(fabsf(A.tl_mn[2] - ro.z), fabsf(A.tl_mx[2] - ro.z));
+          const float mw = fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f;
+          const V3 t_ka = mk((ro.x + mw) * ria.x, (ro.y + mw) * ria.y, (ro.z + mw) * ria.z);
+          const V3 t_kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);
+          while (t_pend != TL_NONE && !(t_pend & BVH_LEAF_FLAG)) {
+            const CADDR DNode &N = A.nodes[A.tlas_begin + t_pend];
+            auto t_hits = [&](const auto &mn, const auto &mx) -> mask_t {
+              const float t1x = __builtin_fmaf(mn[0], ria.x, -t_ka.x), t2x = __builtin_fmaf(mx[0], ria.x, -t_kb.x);
+              const float t1y = __builtin_fmaf(mn[1], ria.y, -t_ka.y), t2y = __builtin_fmaf(mx[1], ria.y, -t_kb.y);
+              const float t1z = __builtin_fmaf(mn[2], ria.z, -t_ka.z), t2z = __builtin_fmaf(mx[2], ria.z, -t_kb.z);
+              const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+              const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+              return lv_m & ~(FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, t_lim, FC_OGT));
+            };
+            const bool hl = t_hits(N.lmn, N.lmx) != 0ull, hr = t_hits(N.rmn, N.rmx) != 0ull;
+            const uint32_t dl = N.left, dr = N.right;
+            if (hl && hr) {
+              asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
+                           : "+v"(t_stack_v)
+                           : "s"(__builtin_amdgcn_readfirstlane(dr)), "s"(__builtin_amdgcn_readfirstlane(t_sp))
+                           : "m0");
+              t_sp++;
+              t_pend = dl;
+            } else if (hl) {
+              t_pend = dl;
+            } else if (hr) {
+              t_pend = dr;
+            } else if (t_sp != 0u) {
+              t_sp--;
+              t_pend = (uint32_t)__builtin_amdgcn_readlane((int)t_stack_v, (int)t_sp);
+            } else {
+              t_pend = TL_NONE;
+            }
+          }
+        }
+        if (t_pend == TL_NONE) break;
+        const CADDR DObj &O = A.meshes[t_pend & 0xFFFFFFu];
+        // advance first, so that `continue` below moves on to the next mesh
+        if (t_sp != 0u) {
+          t_sp--;
+          t_pend = (uint32_t)__builtin_amdgcn_readlane((int)t_stack_v, (int)t_sp);
+        } else {
+          t_pend = TL_NONE;
+        }
+        const uint32_t i = O.index;
+        bool ok = false;
+        float cand = INFINITY;
+        int ctri = -1;
+        {
+          // Everything in this branch works on 64-bit lane masks (v_cmp results kept in SGPRs and
+          // combined on the scalar unit) instead of per-lane booleans.
+          TSTAMP(t_mesh0);
+          const mask_t live_m = BALLOT(live);
+          // ---- mesh::bound_intersects, default_schema.hpp:99-114 ----
+          // The reference's slab test needs three IEEE divisions (1/dir) per ray.  With 1-ulp
+          // reciprocals every t is within 3 ulp of the exact one and tmin/tmax are 1-Lipschitz in
+          // the t's, so lanes whose tmin/tmax differ by more than dl = 2^-20 * max|t| are decided
+          // without them; only borderline lanes (or NaN/inf: axis-parallel rays) take the exact path.
+          mask_t bb_m;
+          {
+            const float a1x = (O.f[0] - ro.x) * ria.x, a2x = (O.f[3] - ro.x) * ria.x;
+            const float a1y = (O.f[1] - ro.y) * ria.y, a2y = (O.f[4] - ro.y) * ria.y;
+            const float a1z = (O.f[2] - ro.z) * ria.z, a2z = (O.f[5] - ro.z) * ria.z;
+            const float lo_a = fmaxf(fmaxf(fmaxf(fminf(a1x, a2x), fminf(a1y, a2y)), fminf(a1z, a2z)), 0.0f);
+            const float hi_a = fminf(fminf(fmaxf(a1x, a2x), fmaxf(a1y, a2y)), fmaxf(a1z, a2z));
+            const float tabs = fmaxf(fmaxf(fmaxf(fabsf(a1x), fabsf(a2x)), fmaxf(fabsf(a1y), fabsf(a2y))),
+                                     fmaxf(fabsf(a1z), fabsf(a2z)));
+            const float dl = tabs * 0x1p-20f;
+            const mask_t def_hit = FCMP(lo_a + dl, hi_a, FC_OLT);
+            const mask_t def_miss = FCMP(lo_a - dl, hi_a, FC_OGT);
+            // axis-parallel rays always take the exact path: the reference's inf/NaN min/max semantics
+            // (0 x inf when the origin sits exactly on a box face) are not what finite arithmetic gives
+            const mask_t border = live_m & (~(def_hit | def_miss) | FCMP(ria_big, 1e29f, FC_OGE));
+            bb_m = live_m & def_hit & ~border;
+            if (border != 0ull) {
+              if (!have_rinv) {  // wave-uniform: the exact reciprocals are computed at most once per cast
+                float ox = rd.x, oy = rd.y, oz = rd.z;
+                PIN3(ox, oy, oz);  // keeps the three IEEE divisions in this rarely-taken branch (no hoisting)
+                rinv = mk(1.0f / ox, 1.0f / oy, 1.0f / oz);  // default_schema.hpp:103
+                have_rinv = true;
+              }
+              float tmin = 0.0f, tmax = INFINITY;
+              float t1 = (O.f[0] - ro.x) * rinv.x, t2 = (O.f[3] - ro.x) * rinv.x;
+              tmin = smin(smax(t1, tmin), smax(t2, tmin));
+              tmax = smax(smin(t1, tmax), smin(t2, tmax));
+              t1 = (O.f[1] - ro.y) * rinv.y; t2 = (O.f[4] - ro.y) * rinv.y;
+              tmin = smin(smax(t1, tmin), smax(t2, tmin));
+              tmax = smax(smin(t1, tmax), smin(t2, tmax));
+              t1 = (O.f[2] - ro.z) * rinv.z; t2 = (O.f[5] - ro.z) * rinv.z;
+              tmin = smin(smax(t1, tmin), smax(t2, tmin));
+              tmax = smax(smin(t1, tmax), smin(t2, tmax));
+              bb_m |= border & FCMP(tmin, tmax, FC_OLE);
+            }
+          }
+          if (bb_m == 0ull) {  // no lane of this wave needs the mesh
+            TSTAMP(t_mesh_skip);
+            TACC(1, t_mesh0, t_mesh_skip);
+            continue;
+          }
+          const mask_t bb0_m = bb_m;
+          const uint32_t beg = O.tri_begin, cnt = O.tri_count;
+          if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
+          if (STATS) st[4]++;
+          // ---- mesh::intersect, default_schema.hpp:125-144: smallest valid t, FIRST triangle in
+          //      file order on ties (strict < over file order)  ==  lexicographic min of (t, orig) ----
+          float mt = INFINITY;
+          int mk_ = -1;
+          uint32_t morig = 0xFFFFFFFFu;
+          const bool anyhit_now = ANYHIT && shadow_cast;
+          // no triangle/node beyond `lim` can matter: the light for a deciding shadow ray, else the
+          // nearest hit so far (other objects, then this mesh)
+          float lim = anyhit_now ? light_dist : best;
+
+          // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
+          auto tri_test = [&](const auto &T, uint32_t tri_index, mask_t lanes_m) {
+            mask_t c_m = lanes_m;
+            if (STATS) st[2]++;
+            const float dx = T.px - ro.x, dy = T.py - ro.y, dz = T.pz - ro.z;
+            if (PREFILTER) {
+              // Conservative reject test.  Same quantities as the exact test
+              // (alpha = det[a b c], A1 = det[d b c], A2 = det[a d c]) evaluated with FMAs
+              // as triple products; every comparison carries a slack E that bounds both this
+              // evaluation's and the reference's rounding, and a
+              // NaN anywhere makes the lane a candidate.
+              const float alpha = __builtin_fmaf(rd.x, T.nx, __builtin_fmaf(rd.y, T.ny, rd.z * T.nz));
+              const float qx = __builtin_fmaf(dy, rd.z, -(dz * rd.y));
+              const float qy = __builtin_fmaf(dz, rd.x, -(dx * rd.z));
+              const float qz = __builtin_fmaf(dx, rd.y, -(dy * rd.x));
+              const float A1n = __builtin_fmaf(T.bx, qx, __builtin_fmaf(T.by, qy, T.bz * qz));  // = -A1
+              const float A2 = __builtin_fmaf(T.ax, qx, __builtin_fmaf(T.ay, qy, T.az * qz));
+              const uint32_t sgn = __float_as_uint(alpha) & 0x80000000u;
+              const float sA1 = __uint_as_float(__float_as_uint(A1n) ^ sgn ^ 0x80000000u);
+              const float sA2 = __uint_as_float(__float_as_uint(A2) ^ sgn);
+              const float absa = fabsf(alpha);
+              const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+              const float E = fmaxf(dmax * T.ke, T.ke2) * cmax;  // kappa * max(dmax,emax) * emax * cmax
+              const mask_t rej = FCMP(sA1, -E, FC_OLT) | FCMP(sA2, -E, FC_OLT) | FCMP(sA1 + sA2, absa + E, FC_OGT);
+              c_m = lanes_m & (~rej | FCMP(absa, E, FC_OLE));
+            }
+            if (c_m == 0ull) return;
+            if (STATS) st[3]++;
+            bool retire = false;  // any-hit: this lane found its occluder
+            if (INVB(c_m)) {
+              // ---- triangle::intersect, default_schema.hpp:57-78: the four determinants in the
+              //      reference's operation order ----
+              const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
+              const V3 d = mk(dx, dy, dz);
+              const float alpha = det3(a, b, rd);
+              const float A1 = det3(d, b, rd), A2 = det3(a, d, rd), A0 = det3(a, b, d);
+              // The three IEEE divisions (beta, gamma, t0) decide five comparisons and deliver t0.
+              // 1-ulp-reciprocal quotients are within 2^-21 relative of the exact ones, so with a
+              // 2^-18 margin (and an absolute floor for zero/denormal quotients) most lanes are
+              // decided without dividing; t0 itself is divided only where its value can matter.
+              const float r = __builtin_amdgcn_rcpf(alpha);
+              const float bq = A1 * r, gq = A2 * r, tq = A0 * r, sq = bq + gq;
+              const float eb = fabsf(bq) * 0x1p-18f + 1e-30f, eg = fabsf(gq) * 0x1p-18f + 1e-30f;
+              const float es = (fabsf(bq) + fabsf(gq) + 1.0f) * 0x1p-16f;
+              const float et = fabsf(tq) * 0x1p-18f + 1e-30f;
+              const bool def_rej = (bq < -eb) | (gq < -eg) | (sq > 1.0f + es) | (tq < min_t - et);
+              const bool def_acc = (bq > eb) & (gq > eg) & (sq < 1.0f - es) & (tq > min_t + et) & (fabsf(tq) < 1e37f);
+              bool acc = def_acc;
+              float t0 = tq;
+              bool exact_t = false;
+              if (!(def_rej | def_acc)) {
+                // borderline (or NaN/inf): the reference's own arithmetic
+                const float beta = A1 / alpha, gamma = A2 / alpha;
+                t0 = A0 / alpha;
+                exact_t = true;
+                acc = beta >= 0 && gamma >= 0 && beta + gamma <= 1 && __builtin_isfinite(t0) && min_t <= t0;
+              }
+              if (acc) {
+                if (anyhit_now) {
+                  // A deciding shadow ray only asks whether some valid t lies in (min_t, light_dist).
+                  // tq is within et of the exact t0 and already > min_t + et, so divide only when tq is
+                  // within et of the light distance.
+                  if (!exact_t && !(tq + et < light_dist) && !(tq - et >= light_dist)) t0 = A0 / alpha;
+                  if (t0 > min_t && t0 < light_dist) {
+                    best = t0; bobj = (int)i;   // any value < light_dist: the handler only compares
+                    retire = true;
+                  }
+                } else {
+                  // the exact value of t0 matters only if it can beat or tie the nearest hit so far
+                  if (!exact_t && !(tq - et > lim)) { t0 = A0 / alpha; exact_t = true; }
+                  const uint32_t orig = T.orig;
+                  if (exact_t && (t0 < mt || (t0 == mt && orig < morig))) {
+                    mt = t0; mk_ = (int)tri_index; morig = orig;
+                    lim = fminf(lim, mt);
+                  }
+                }
+              }
+            }
+            if (ANYHIT) {
+              const mask_t rm = BALLOT(retire);
+              bb_m &= ~rm;
+            }
+          };
+
+          if (BVH) {
+            // Walk of the mesh's BVH by the whole wave together (bvh.h): an inner node holds BOTH
+            // children's boxes, so a child no lane touches is never loaded and leaves cost no node
+            // load.  Pending inner children wait on a wave-uniform stack kept in the lanes of ONE
+            // VGPR (v_writelane / v_readlane); the child on the near side of the split axis goes
+            // first.  The box test is conservative: boxes are widened by m = 2^-15 x (largest
+            // |coordinate difference| between the ray origin and the mesh), applied in t-space as a
+            // slack of 2*m*max|1/dir|; a NaN enters the box.
+            // The box test is conservative: every box is widened in WORLD space by
+            //   m = 2^-14 x (largest |coordinate difference| between the ray origin and the mesh box)
+            // per axis ((mn - m - o)/d and (mx + m - o)/d, folded into the two FMA constants below), far
+            // above the rounding of either this test or the reference's triangle test (DESIGN.md
+            // §bvh); a NaN (0 x inf for an axis-parallel ray) drops that axis' constraint.
+            const float gx = fmaxf(fabsf(O.f[0] - ro.x), fabsf(O.f[3] - ro.x));
+            const float gy = fmaxf(fabsf(O.f[1] - ro.y), fabsf(O.f[4] - ro.y));
+            const float gz = fmaxf(fabsf(O.f[2] - ro.z), fabsf(O.f[5] - ro.z));
+            const float mw = fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f;
+            const V3 ka = mk((ro.x + mw) * ria.x, (ro.y + mw) * ria.y, (ro.z + mw) * ria.z);  // for box minima
+            const V3 kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);  // for box maxima
+            const CADDR DNode *nodes = A.nodes + O.node_begin;
+            // direction signs of the first lane that needs the mesh decide the visiting order (speed only)
+            const uint32_t lead = (uint32_t)__builtin_ctzll(bb_m);
+            const uint32_t neg_bits = (__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31) |
+                                      ((__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31) << 1) |
+                                      ((__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31) << 2);
+            auto box_hits = [&](const auto &mn, const auto &mx) -> mask_t {
+              const float t1x = __builtin_fmaf(mn[0], ria.x, -ka.x), t2x = __builtin_fmaf(mx[0], ria.x, -kb.x);
+              const float t1y = __builtin_fmaf(mn[1], ria.y, -ka.y), t2y = __builtin_fmaf(mx[1], ria.y, -kb.y);
+              const float t1z = __builtin_fmaf(mn[2], ria.z, -ka.z), t2z = __builtin_fmaf(mx[2], ria.z, -kb.z);
+              const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+              const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+              // reject only on a definite miss (NaN compares false -> the box is entered)
+              const mask_t miss = FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, lim, FC_OGT);
+              return bb_m & ~miss;
+            };
+            auto leaf = [&](uint32_t desc, mask_t lanes) {
+              const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
+              for (uint32_t k = 0; k < n_l; ++k) {
+                if (VMEM) {
+                  uint32_t iv = first + k;
+                  HIDE_UNIFORM(iv);
+                  const DTri Tv = A.tris_g[iv];
+                  tri_test(Tv, first + k, lanes & bb_m);
+                } else {
+                  tri_test(A.tris[first + k], first + k, lanes & bb_m);
+                }
+              }
+            };
+            uint32_t cur = O.bvh_root;
+            if (cur & BVH_LEAF_FLAG) {
+              leaf(cur, bb_m);  // the whole mesh fits one leaf
+            } else {
+              uint32_t stack_v = 0;  // lane k of this VGPR = stack slot k (depth <= BVH_MAX_DEPTH < 64)
+              uint32_t sp = 0;
+              for (;;) {
+                if (STATS) st[1]++;
+                mask_t hl, hr;
+                uint32_t n_left, n_right, n_axis;
+                if (VMEM) {
+                  uint32_t cv = O.node_begin + cur;
+                  HIDE_UNIFORM(cv);
+                  const DNode Nv = A.nodes_g[cv];
+                  hl = box_hits(Nv.lmn, Nv.lmx);
+                  hr = box_hits(Nv.rmn, Nv.rmx);
+                  n_left = __builtin_amdgcn_readfirstlane(Nv.left);
+                  n_right = __builtin_amdgcn_readfirstlane(Nv.right);
+                  n_axis = __builtin_amdgcn_readfirstlane(Nv.axis);
+                } else {
+                  const CADDR DNode &N = nodes[cur];
+                  hl = box_hits(N.lmn, N.lmx);
+                  hr = box_hits(N.rmn, N.rmx);
+                  n_left = N.left; n_right = N.right; n_axis = N.axis;
+                }
+                // near child first
+                const bool swap = ((neg_bits >> n_axis) & 1u) != 0u;
+                const uint32_t d0 = swap ? n_right : n_left, d1 = swap ? n_left : n_right;
+                const mask_t h0 = swap ? hr : hl, h1 = swap ? hl : hr;
+                uint32_t next = 0xFFFFFFFFu;
+                if (h0 != 0ull) {
+                  if (d0 & BVH_LEAF_FLAG) leaf(d0, h0);
+                  else next = d0;
+                }
+                if (h1 != 0ull && !(ANYHIT && bb_m == 0ull)) {
+                  if (d1 & BVH_LEAF_FLAG) {
+                    // d0's leaf may have pulled `lim` in: lanes whose far box now lies beyond it drop out
+                    leaf(d1, h1);
+                  } else if (next == 0xFFFFFFFFu) {
+                    next = d1;
+                  } else {
+                    // v_writelane_b32: value and lane select are both wave-uniform; gfx9 allows one SGPR
+                    // operand per VALU instruction, so the lane select travels in M0
+                    // (readfirstlane restates that both are wave-uniform; the compiler cannot always prove it)
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
+                                 : "+v"(stack_v)
+                                 : "s"(__builtin_amdgcn_readfirstlane(d1)), "s"(__builtin_amdgcn_readfirstlane(sp))
+                                 : "m0");
+                    sp++;
+                  }
+                }
+                if (ANYHIT) {
+                  if (bb_m == 0ull) break;
+                }
+                if (next == 0xFFFFFFFFu) {
+                  if (sp == 0) break;
+                  sp--;
+                  next = __builtin_amdgcn_readlane(stack_v, sp);
+                }
+                cur = next;
+              }
+            }
+          } else {
+            for (uint32_t k = 0; k < cnt; ++k) {
+              tri_test(A.tris[beg + k], beg + k, bb_m);  // wave-uniform: one s_load_dwordx16
+              if (ANYHIT) {
+                if (bb_m == 0ull) break;
+              }
+            }
+          }
+          if (ANYHIT) live = live && !INVB(bb0_m & ~bb_m);  // lanes retired inside the mesh
+          ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
+          cand = mt;
+          ctri = mk_;
+          TSTAMP(t_mesh1);
+          TACC(1, t_mesh0, t_mesh1);
+
+        }
+        // ray_cast.hpp:43 — strict <, first object in scene order wins ties
+        if (live && ok && cand > min_t && (cand < best || (cand == best && (int)i < bobj))) {
+          best = cand;
+          bobj = (int)i;
+          btri = ctri;
+        }
+        if (ANYHIT) {
+          if (shadow_cast && live && ok && cand > min_t && cand < light_dist) live = false;
+        }
       }
     }
     const bool was_hit = bobj >= 0;
@@ -869,6 +956,11 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   KArgs A;
   A.objs = (const CADDR DObj *)L.objs;
   A.oloop = (const CADDR DObj *)L.oloop;
+  A.meshes = (const CADDR DObj *)L.meshes;
+  A.n_mesh = L.n_mesh;
+  A.tlas_root = L.tlas_root;
+  A.tlas_begin = L.tlas_begin;
+  for (int q = 0; q < 3; q++) { A.tl_mn[q] = L.tl_mn[q]; A.tl_mx[q] = L.tl_mx[q]; }
   A.planes = (const CADDR DPlane *)L.planes;
   A.n_oloop = L.n_oloop;
   A.n_planes = L.n_planes;

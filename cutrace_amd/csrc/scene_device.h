@@ -109,7 +109,10 @@ struct DRows {
 
 struct RenderLaunch {
   const DObj *objs;        // every object, scene order (hit records)
-  const DObj *oloop;       // the non-plane objects, scene order (the generic loop)
+  const DObj *oloop;       // spheres and stand-alone triangles, scene order (sequential loop)
+  const DObj *meshes;      // non-empty meshes in top-level-BVH leaf order
+  uint32_t n_mesh, tlas_root, tlas_begin;
+  float tl_mn[3], tl_mx[3];
   const DPlane *planes;
   uint32_t n_oloop, n_planes;
   const DTri *tris;
