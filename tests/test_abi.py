@@ -56,3 +56,40 @@ def test_no_gpu_means_loud_failure_not_fallback(ca):
         assert "ctr_scene_create failed" in str(e)
     else:
         raise AssertionError("ctr_scene_create succeeded without a GPU?")
+
+
+def test_scene_create_validates_the_description_before_touching_the_gpu(ca):
+    """Malformed descriptions are rejected with CTR_E_INVALID (1) — the kernel trusts these indices."""
+    import ctypes as C
+    from tests.conftest import load_scene
+    L = _lib.hip_lib()
+    s = load_scene(ca, "bunny")
+    d = s.desc.contents
+
+    def create(desc):
+        h = C.c_void_p()
+        st = L.ctr_scene_create(C.byref(desc), 0, C.byref(h))
+        if st == 0:
+            L.ctr_scene_destroy(h)
+        return st
+
+    def clone():
+        c = _lib.SceneDesc()
+        C.memmove(C.byref(c), C.byref(d), C.sizeof(_lib.SceneDesc))
+        objs = (_lib.Object * d.n_objects)()
+        C.memmove(objs, d.objects, C.sizeof(objs))
+        c.objects = C.cast(objs, C.POINTER(_lib.Object))
+        return c, objs
+
+    c, objs = clone()
+    objs[1].mat_idx = 99
+    assert create(c) == 1 and b"material index" in L.ctr_last_error()
+    c, objs = clone()
+    objs[0].tri_count = 5000
+    assert create(c) == 1 and b"triangle range" in L.ctr_last_error()
+    c, objs = clone()
+    objs[2].type = 7
+    assert create(c) == 1 and b"bad type" in L.ctr_last_error()
+    h = C.c_void_p()
+    assert L.ctr_scene_create(None, 0, C.byref(h)) == 1
+    assert L.ctr_render(None, C.c_float(1e-3), 5, None, None, None, None, None) == 1
