@@ -45,6 +45,8 @@ def parse_args():
     p.add_argument("--bounces", type=int, default=5)
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     p.add_argument("--variant", type=int, default=0)
+    p.add_argument("--skip-probe", action="store_true",
+                   help="skip the untimed image-order launches after the timed region (profiling runs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-div", type=int, default=0, help="CPU baseline renders 1/div of the row blocks (0=auto)")
     p.add_argument("--of", type=int, default=0, help="diagnostic: time the tiled batch render of one rank of N (no gather)")
@@ -172,6 +174,17 @@ def main():
     dt = time.perf_counter() - t0
 
     kern_ms = [a.elapsed_time(b) for a, b in events]
+    # for the record (untimed): the same launch with tiles dispatched in image order, i.e. what the
+    # first launch of a shape costs before the scheduling feedback exists
+    kern_io = None
+    if not args.skip_probe:
+        ds.set_variant(args.variant | ca.VAR_NO_REORDER)
+        ev_io = []
+        for _ in range(3):
+            render_step(ev_io)
+        barrier()
+        kern_io = min(a.elapsed_time(b) for a, b in ev_io)
+        ds.set_variant(args.variant)
     t = torch.tensor([dt, float(rays_rank_step), sum(kern_ms) / max(1, len(kern_ms))], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone()
@@ -210,6 +223,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
                                    f"{frames} frame(s)/step row-tiled over {world} GPU(s), gather to rank 0",
+                       "tile_order": "expensive tiles first, costs recorded by the previous launch of the same "
+                                     "shape (first launch of a shape: image order)",
+                       "kernel_ms_image_order": kern_io,
                        "frames_per_step": frames, "rays_per_step": rays_step,
                        "frame_ms": dt_max / args.steps * 1e3 / frames,
                        "unique_mrays_per_s": (rays_step - frames * w * h) * args.steps / dt_max / 1e6},

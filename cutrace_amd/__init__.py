@@ -24,6 +24,7 @@ VAR_STATS = 16
 VAR_EXACT_POW = 32
 VAR_VMEM = 64
 VAR_SMEM = 128
+VAR_NO_REORDER = 256
 
 
 @contextlib.contextmanager

@@ -118,6 +118,12 @@ struct ctr_scene {
   unsigned long long *d_counters = nullptr;
   unsigned long long *d_shards = nullptr;  // CTR_SHARDS x CTR_SHARD_WORDS, zero between launches
   size_t out_px = 0;
+  // tile scheduling feedback (include/cutrace_amd.h "Tile scheduling")
+  uint32_t *d_cost = nullptr, *d_order = nullptr;
+  uint32_t order_age = 0;  // launches since d_order was last rebuilt
+  uint64_t order_cap = 0;
+  uint64_t order_key[6] = {0, 0, 0, 0, 0, 0};
+  bool order_valid = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mtx;
 
@@ -206,6 +212,40 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.first_frame = 0;
   L.n_frames = 1;
   L.frame_stride_px = 0;
+}
+
+// Attach the tile-order buffers to a launch: use the stored order when the launch has the shape the
+// order was measured on, and have the launch record costs + sort them for the next one.
+int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
+  L.order = nullptr;
+  L.cost = nullptr;
+  L.order_next = nullptr;
+  if ((s->user_variant & (CTR_VAR_NO_REORDER | CTR_VAR_STATS)) || count) return CTR_OK;
+  const uint64_t n = ctr_launch_waves(L);
+  if (n == 0 || n > 0x7FFFFFFFull) return CTR_OK;
+  if (n > s->order_cap) {
+    if (s->d_cost) (void)hipFree(s->d_cost);
+    if (s->d_order) (void)hipFree(s->d_order);
+    s->d_cost = s->d_order = nullptr;
+    s->order_cap = 0;
+    s->order_valid = false;
+    HIP_TRY(hipMalloc((void **)&s->d_cost, n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&s->d_order, n * sizeof(uint32_t)));
+    s->order_cap = n;
+  }
+  const uint64_t key[6] = {n, ((uint64_t)L.w << 32) | L.h, ((uint64_t)L.rows.row_begin << 32) | L.rows.row_end,
+                           ((uint64_t)L.rows.block_rows << 32) | L.rows.n_parts,
+                           ((uint64_t)L.rows.part << 32) | L.rows.part_stride, L.n_frames};
+  const bool same = s->order_valid && memcmp(key, s->order_key, sizeof(key)) == 0;
+  if (same) L.order = s->d_order; else s->order_age = 0;
+  memcpy(s->order_key, key, sizeof(key));
+  s->order_valid = true;  // after this launch d_order holds an order measured on this shape
+  L.cost = s->d_cost;
+  // Costs barely move from launch to launch: the order is rebuilt after the first two launches of a
+  // shape (the second one measured under the new order) and then after every 8th.
+  if (s->order_age < 2 || s->order_age % 8 == 0) L.order_next = s->d_order;
+  s->order_age++;
+  return CTR_OK;
 }
 
 int check_args(const ctr_scene *s, int bounces) {
@@ -459,7 +499,7 @@ void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
-                  (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters, (void *)s->d_shards})
+                  (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -531,6 +571,10 @@ int ctr_render_device_batch(ctr_scene *s, float fudge, int bounces, const ctr_ro
   L.normal = (float *)d_normal3;
   L.counters = (unsigned long long *)d_counters;
   L.variant = s->kernel_variant(false);
+  {
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if ((st = attach_order(s, L, false))) return st;
+  }
   int e = ctr_launch_render(L, hip_stream);
   if (e) return hip_fail((hipError_t)e, "render kernel launch");
   return CTR_OK;
@@ -560,6 +604,7 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   L.normal = s->d_normal;
   L.counters = s->d_counters;
   L.variant = s->kernel_variant(count);
+  if ((st = attach_order(s, L, count))) return st;
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), nullptr));
   HIP_TRY(hipEventRecord(s->ev0, nullptr));
   int e = ctr_launch_render(L, nullptr);

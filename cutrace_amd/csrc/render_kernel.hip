@@ -132,6 +132,8 @@ struct KArgs {
   uint32_t has_mesh;
   uint32_t nf;        // LDS dwords per stack frame: 6, or 12 when some material reflects AND transmits
   uint32_t frames;    // LDS stack frames per lane (= max(bounces, 1))
+  const CADDR uint32_t *order;  // dispatch slot -> wave (tile) index, or null = identity
+  uint32_t *cost;               // per wave (tile): shader-clock ticks it took, or null
 };
 
 enum { M_RADIANCE = 0, M_SHADOW = 1, M_DONE = 2 };
@@ -146,7 +148,11 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   constexpr bool ANYHIT = (KV & KV_ANYHIT) != 0;
   constexpr bool COUNT = (KV & KV_COUNT) != 0;
   constexpr bool BVH = (KV & KV_BVH) != 0;
+#ifdef CTR_WAVELOG
+  constexpr bool STATS = true;
+#else
   constexpr bool STATS = (KV & KV_STATS) != 0;
+#endif
   constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
   // VMEM: BVH nodes and triangles travel through the vector memory path (same address in every
   // lane, values in VGPRs) instead of the scalar cache.  The scalar cache sustains very few
@@ -168,14 +174,24 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
 #define TACC(i, a, b)
 #endif
 
+#ifdef CTR_WAVELOG
+  const unsigned long long wl_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+#endif
   const uint32_t w = A.w, h = A.h;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
-  const uint32_t wave = (blockIdx.x * WAVES_PER_WG) + wave_in_wg;
+  const uint32_t slot = (blockIdx.x * WAVES_PER_WG) + wave_in_wg;
   const uint32_t tiles_x = (w + TW - 1) / TW;
   const uint32_t tiles_y = (A.rows.n_rows + TH - 1) / TH;
   const uint32_t tiles_frame = tiles_x * tiles_y;
-  if (wave >= tiles_frame * A.n_frames) return;  // whole wave exits together
+  if (slot >= tiles_frame * A.n_frames) return;  // whole wave exits together
+  // Dispatch order.  Waves differ 10x in cost and the hardware hands them out in blockIdx order, so
+  // with tiles in image order the last quarter of a frame is a tail of a few slow waves on an
+  // otherwise empty GPU.  Every launch records what each tile cost; the next launch of the same
+  // shape starts the expensive tiles first (longest-processing-time-first list scheduling).
+  const unsigned long long t_wave0 = __builtin_readcyclecounter();
+  const uint32_t wave = A.order ? A.order[slot] : slot;
+  if (wave >= tiles_frame * A.n_frames) return;  // cannot happen with a valid order; never write out of bounds
   // batch of frames (a camera path): frame-major waves, one camera per frame (wave-uniform)
   const uint32_t frame = wave / tiles_frame;
   const uint32_t tile = wave - frame * tiles_frame;
@@ -774,7 +790,10 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           const V3 nd = rd;  // the shadow ray's direction IS the normalized direction to the light
           const float fd = smax(0.0f, vdot(nn, nd));
           const V3 ld = vmul(diffuse, color);
-          const V3 hv = vnormalized(vadd(vscale(in_dn, -1.0f), nd));
+          const V3 hsum = vadd(vscale(in_dn, -1.0f), nd);
+          // the half vector feeds only the specular colour term: with the fast specular path its
+          // normalisation uses the 1-ulp v_rsq_f32 instead of IEEE sqrt + division
+          const V3 hv = FASTPOW ? vscale(hsum, __builtin_amdgcn_rsqf(vdot(hsum, hsum))) : vnormalized(hsum);
           const float sx = smax(0.0f, vdot(nn, hv));
           float fs;
           if (FASTPOW) {
@@ -883,9 +902,23 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   }
 #undef STK
 
+  if (A.cost && lane == 0) {
+    const unsigned long long dt = (__builtin_readcyclecounter() - t_wave0) >> 6;
+    const uint32_t c = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+    A.cost[wave] = c;
+  }
+#ifdef CTR_WAVELOG
+  // diagnostic build only: lane 0 overwrites its pixel's normal with {start, end} of the wave (10 ns ticks)
+  if (lane == 0 && in_image) {
+    const unsigned long long wl_end = __builtin_amdgcn_s_memrealtime();
+    normal_out[px_id * 3 + 0] = __uint_as_float((uint32_t)wl_start);
+    normal_out[px_id * 3 + 1] = __uint_as_float((uint32_t)wl_end);
+    normal_out[px_id * 3 + 2] = __uint_as_float((uint32_t)(st[1] | (st[2] << 12) | (st[3] << 24)));  // nodes, prefilters, exact
+  }
+#endif
   // ---- per-wave reductions -> 2-3 atomics per wave, spread over CTR_SHARDS cache lines ----
   // (all waves adding into ONE address serialise at the memory side: 0.76 ms per 1080p frame,
-  //  measured; one 128-byte shard per wave%CTR_SHARDS costs nothing measurable.  fold_shards
+  //  measured; one 128-byte shard per wave%CTR_SHARDS costs nothing measurable.  after_render
   //  then adds the shards into the caller's counters and clears them.)
   if (counters) {
     unsigned long long c = n_casts;
@@ -915,10 +948,10 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   }
 }
 
-// one block of CTR_SHARDS threads: thread t owns shard t; wave-level reduction, then one LDS atomic per
+// ---- after_render: block 0 folds the counter shards, block 1 builds the next dispatch order ----
+// block of CTR_SHARDS threads: thread t owns shard t; wave-level reduction, then one LDS atomic per
 // wave and word; adds into out[0..13] (max for word 1) and zeroes the shards for the next launch
-__global__ __launch_bounds__(CTR_SHARDS) void fold_shards(unsigned long long *__restrict__ shards,
-                                                          unsigned long long *__restrict__ out) {
+__device__ void fold_block(unsigned long long *__restrict__ shards, unsigned long long *__restrict__ out) {
   constexpr int NW = 14;
   __shared__ unsigned long long acc[NW];
   if (threadIdx.x < NW) acc[threadIdx.x] = 0ull;
@@ -949,6 +982,101 @@ __global__ __launch_bounds__(CTR_SHARDS) void fold_shards(unsigned long long *__
       if (threadIdx.x == 1) atomicMax(&out[1], r); else atomicAdd(&out[threadIdx.x], r);
     }
   }
+}
+
+// block of CTR_COST_BINS threads: counting sort of the launch's waves by cost class, expensive first:
+// order[slot] = wave.  64 classes (8 per octave below the maximum) x 16 sub-bins by wave index —
+// the sub-bins only spread the LDS atomics of neighbouring waves, which usually share a class.
+// Any permutation is a correct order; cost only shapes the tail of the next launches.
+__device__ void order_block(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
+  __shared__ uint32_t scan[CTR_COST_BINS];
+  __shared__ uint32_t wsum[CTR_COST_BINS / 64];
+  __shared__ uint32_t smax;
+  constexpr uint32_t U = 8;
+  const uint32_t t = threadIdx.x, ln = t & 63u, wv = t >> 6;
+  scan[t] = 0u;
+  if (t == 0) smax = 1u;
+  __syncthreads();
+  uint32_t m = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += U * CTR_COST_BINS) {
+    uint32_t c[U];
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t i = b0 + k * CTR_COST_BINS + t;
+      c[k] = i < n ? cost[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) m = c[k] > m ? c[k] : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, off);
+    m = o > m ? o : m;
+  }
+  if (ln == 0) atomicMax(&smax, m);
+  __syncthreads();
+  const uint32_t top = __float_as_uint((float)smax);
+  auto bin = [&](uint32_t c, uint32_t i) -> uint32_t {
+    const uint32_t fb = __float_as_uint((float)c);       // exponent | mantissa: log-linear in c
+    uint32_t cls = fb < top ? (top - fb) >> 20 : 0u;     // 1/8 octave steps below the maximum
+    cls = cls > 63u ? 63u : cls;
+    return cls * 16u + (i & 15u);
+  };
+  for (uint32_t b0 = 0; b0 < n; b0 += U * CTR_COST_BINS) {
+    uint32_t c[U];
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t i = b0 + k * CTR_COST_BINS + t;
+      c[k] = i < n ? cost[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t i = b0 + k * CTR_COST_BINS + t;
+      if (i < n) atomicAdd(&scan[bin(c[k], i)], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t v = scan[t];
+  uint32_t x = v;  // inclusive scan inside the wave, then across the 16 waves
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)x, off);
+    if (ln >= (uint32_t)off) x += o;
+  }
+  if (ln == 63u) wsum[wv] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t q = 0; q < wv; q++) base += wsum[q];
+  scan[t] = base + x - v;  // exclusive offset of bin t
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < n; b0 += U * CTR_COST_BINS) {
+    uint32_t c[U];
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t i = b0 + k * CTR_COST_BINS + t;
+      c[k] = i < n ? cost[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t i = b0 + k * CTR_COST_BINS + t;
+      if (i < n) order[atomicAdd(&scan[bin(c[k], i)], 1u)] = i;
+    }
+  }
+}
+
+static_assert(CTR_SHARDS == CTR_COST_BINS, "after_render uses one block size for both jobs");
+__global__ __launch_bounds__(CTR_SHARDS) void after_render(unsigned long long *__restrict__ shards,
+                                                           unsigned long long *__restrict__ counters,
+                                                           const uint32_t *__restrict__ cost,
+                                                           uint32_t *__restrict__ order, uint32_t n) {
+  if (blockIdx.x == 0) {
+    if (shards) fold_block(shards, counters);
+  } else {
+    if (cost) order_block(cost, order, n);
+  }
+}
+
+uint64_t launch_waves(const RenderLaunch &L) {
+  const uint32_t tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
+  return (uint64_t)tiles_x * tiles_y * L.n_frames;
 }
 
 template <uint32_t KV>
@@ -985,9 +1113,10 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.has_mesh = L.has_mesh;
   A.nf = L.need_cold_frames ? 12u : 6u;
   A.frames = (uint32_t)(L.bounces > 0 ? L.bounces : 1);
+  A.order = (const CADDR uint32_t *)L.order;
+  A.cost = L.cost;
   const size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
-  const uint32_t tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
-  const uint64_t waves = (uint64_t)tiles_x * tiles_y * L.n_frames;
+  const uint64_t waves = launch_waves(L);
   if (waves > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
   if (waves == 0) return 0;
   const uint32_t grid = (uint32_t)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
@@ -995,7 +1124,10 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   unsigned long long *shards = L.counters ? L.shards : nullptr;
   hipLaunchKernelGGL(render_kernel<KV>, dim3(grid), dim3(WG_THREADS), lds_bytes, stream, A, L.depth, L.color, L.normal,
                      shards);
-  if (shards) hipLaunchKernelGGL(fold_shards, dim3(1), dim3(CTR_SHARDS), 0, stream, shards, L.counters);
+  const bool reorder = L.cost && L.order_next;
+  if (shards || reorder)
+    hipLaunchKernelGGL(after_render, dim3(reorder ? 2 : 1), dim3(CTR_SHARDS), 0, stream, shards, L.counters,
+                       reorder ? L.cost : nullptr, L.order_next, (uint32_t)waves);
   return (int)hipGetLastError();
 }
 
@@ -1014,6 +1146,8 @@ int launch_main(const RenderLaunch &L, hipStream_t s) {
 }
 
 }  // namespace
+
+uint64_t ctr_launch_waves(const RenderLaunch &L) { return launch_waves(L); }
 
 int ctr_launch_render(const RenderLaunch &L, void *stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -136,13 +136,22 @@ struct RenderLaunch {
   unsigned long long *shards;    // scene-owned CTR_SHARDS x CTR_SHARD_WORDS scratch the kernel adds into
   unsigned long long *counters;  // [0] ray_count, [1] max-depth bits, [2] AABB-hit triangle count (KV_COUNT), [4..9] KV_STATS
   uint32_t variant;
+  // tile scheduling (render_kernel.hip "Dispatch order"): all three may be null
+  const uint32_t *order;  // dispatch slot -> wave index for THIS launch (a permutation of 0..waves-1)
+  uint32_t *cost;         // out: per-wave cost of this launch
+  uint32_t *order_next;   // out (or null = keep the old order): waves sorted by descending cost
+                          // (may alias `order`: written after the render)
 };
 
 // host-callable launcher implemented in render_kernel.hip; returns a hipError_t as int
 int ctr_launch_render(const RenderLaunch &L, void *stream);
+// number of waves (tiles x frames) the launch will dispatch
+uint64_t ctr_launch_waves(const RenderLaunch &L);
 // counters are accumulated in CTR_SHARDS 128-byte shards (see render_kernel.hip) and folded afterwards
 #define CTR_SHARDS 1024
 #define CTR_SHARD_WORDS 16
+// counters of the tile scheduler's counting sort (64 cost classes x 16 sub-bins)
+#define CTR_COST_BINS 1024u
 // maximum `bounces` the kernel supports (explicit per-lane stack depth - 1)
 #define CTR_MAX_BOUNCES 15
 

@@ -200,6 +200,12 @@ int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ct
 #define CTR_VAR_VMEM 64u          /* mesh data through the vector memory path (comparison only; scalar is faster) */
 #define CTR_VAR_SMEM 128u         /* force the scalar-cache path (the default) */
 #define CTR_VAR_STATS 16u         /* diagnostic build: print wave-level work counters to stderr */
+#define CTR_VAR_NO_REORDER 256u   /* always dispatch tiles in image order (see below) */
+/* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
+ * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles
+ * first, which removes the tail of slow waves at the end of a frame.  Results do not depend on the
+ * order.  The first launch of a shape, and every launch under CTR_VAR_NO_REORDER, uses image order.
+ * Consequence: launches on ONE scene handle must be ordered by the caller (one stream at a time). */
 int ctr_set_variant(ctr_scene *scene, uint32_t variant_bits);
 
 /* Algorithmic bytes: 56·n_objects per ray_cast + 48·n_tri for
