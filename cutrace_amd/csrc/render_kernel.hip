@@ -212,7 +212,12 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     y_id = (first + j * A.rows.n_parts) * A.rows.block_rows + (k_row % A.rows.block_rows);
   }
   const bool in_image = x_id < w && k_row < A.rows.n_rows && y_id < A.rows.row_end;
-  const size_t px_id = (size_t)frame * A.frame_stride_px + (size_t)k_row * w + x_id;  // kernel.hpp:54, compact buffer
+  // kernel.hpp:54 (compact buffer).  Recomputed from the lane id at its three uses rather than kept
+  // in two VGPRs for the whole wave: registers, not instructions, are what this kernel is short of.
+  const uint32_t tile_px0 = ty * TH * w + tx * TW;  // wave-uniform
+  auto px_index = [&]() -> size_t {
+    return (size_t)frame * A.frame_stride_px + (size_t)(tile_px0 + (lane / TW) * w + (lane % TW));
+  };
 
   // ---- cam::get_ray, default_schema.hpp:376-386 ----
   V3 ro, rd;
@@ -231,7 +236,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
 
   // ---- per-lane state machine ----
   int mode = in_image ? M_RADIANCE : M_DONE;
-  bool first = true;
+  bool first_trip = true;   // wave-uniform: every in-image lane shades its primary hit in the first trip
+  uint32_t wave_dbits = 0u; // wave-uniform: max finite depth bits of the tile (kernel.hpp:120-125)
   float min_t = A.fudge;
   int sp = 0;               // stack depth; bounces left for the current activation = bounces - sp
   extern __shared__ float lds_stack[];
@@ -245,14 +251,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   float light_dist = 0.f, intensity = 0.f;
   uint32_t mat_i = 0, li = 0;
   V3 out_rgb = mk(0, 0, 0);
-  uint32_t n_casts = in_image ? 1u : 0u;  // the duplicated primary cast (kernel.hpp:52) counts too
+  // casts of the whole wave, counted on the scalar unit; the duplicated primary cast (kernel.hpp:52) counts too
+  unsigned long long n_casts = (unsigned long long)__builtin_popcountll(BALLOT(in_image));
   unsigned long long n_aabb_tris = 0;
-  float my_depth = 0.f;
 
   while (BALLOT(mode != M_DONE) != 0ull) {
     const bool active = mode != M_DONE;
     const bool shadow_cast = mode == M_SHADOW;
-    n_casts += active ? 1u : 0u;
+    n_casts += (unsigned long long)__builtin_popcountll(BALLOT(active));
     if (STATS) { st[0]++; st[5] += __builtin_popcountll(BALLOT(active)); }
 
     // =====================================================================
@@ -487,6 +493,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           int mk_ = -1;
           uint32_t morig = 0xFFFFFFFFu;
           const bool anyhit_now = ANYHIT && shadow_cast;
+          const mask_t anyhit_m = ANYHIT ? BALLOT(shadow_cast) : 0ull;
+          const bool t_filter = A.fudge >= 1e-30f;  // then min_t > 0 in every cast (wave-uniform)
           // no triangle/node beyond `lim` can matter: the light for a deciding shadow ray, else the
           // nearest hit so far (other objects, then this mesh)
           float lim = anyhit_now ? light_dist : best;
@@ -515,7 +523,41 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
               const float E = fmaxf(dmax * T.ke, T.ke2) * cmax;  // kappa * max(dmax,emax) * emax * cmax
               const mask_t rej = FCMP(sA1, -E, FC_OLT) | FCMP(sA2, -E, FC_OLT) | FCMP(sA1 + sA2, absa + E, FC_OGT);
-              c_m = lanes_m & (~rej | FCMP(absa, E, FC_OLE));
+              const mask_t flat_m = FCMP(absa, E, FC_OLE);  // alpha within rounding of 0: always a candidate
+              c_m = lanes_m & (~rej | flat_m);
+              if (c_m == 0ull) return;
+              if (t_filter) {
+                // Second stage, only when some lane survived the first: the ray parameter.
+                // t0 = A0/alpha with A0 = det[a b d] = d.(a x b); E0 bounds the rounding of A0 the
+                // way E does for the other three.  A lane whose t0 is certainly below min_t or
+                // certainly beyond `lim` (the nearest hit so far / the light) cannot be affected by
+                // this triangle — typically the triangle the ray starts on, and hits behind the
+                // current best.
+                const float A0 = __builtin_fmaf(dx, T.nx, __builtin_fmaf(dy, T.ny, dz * T.nz));
+                const float sA0 = __uint_as_float(__float_as_uint(A0) ^ sgn);
+                const float E0 = dmax * T.ke2;
+                const float a_lo = (absa - E) * 0x1.fffep-1f, a_hi = (absa + E) * 0x1.0002p+0f;
+                const mask_t near_m = FCMP(sA0 + E0, min_t * a_lo, FC_OLT);   // t0 < min_t for sure
+                const mask_t far_m = FCMP(sA0 - E0, lim * a_hi, FC_OGT);      // t0 > lim for sure (inf/NaN: no)
+#ifndef CTR_NO_TREJ
+                c_m &= ~(near_m | far_m) | flat_m;
+#endif
+#ifndef CTR_NO_OCC
+                if (anyhit_m != 0ull) {  // wave-uniform: lane masks must never be updated under a per-lane branch
+                  // a deciding shadow ray needs no value at all: clearly inside the triangle and
+                  // clearly between min_t and the light = occluded, no exact test
+                  const mask_t in_m = FCMP(sA1, E, FC_OGT) & FCMP(sA2, E, FC_OGT) & FCMP(sA1 + sA2, absa - E, FC_OLT);
+                  const mask_t tin_m = FCMP(sA0 - E0, min_t * a_hi, FC_OGT) & FCMP(sA0 + E0, light_dist * a_lo, FC_OLT);
+                  const mask_t occ_m = c_m & in_m & tin_m & ~flat_m & anyhit_m;
+                  if (occ_m != 0ull) {
+                    if (INVB(occ_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }  // the handler only asks best < light_dist
+                    bb_m &= ~occ_m;
+                    c_m &= ~occ_m;
+                  }
+                }
+#endif
+                if (c_m == 0ull) return;
+              }
             }
             if (c_m == 0ull) return;
             if (STATS) st[3]++;
@@ -720,6 +762,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     // continuation: what did this lane cast the ray for?
     // =====================================================================
     int act = ACT_NONE;
+    float first_depth = 0.f;  // primary-hit depth of this lane, alive in the first trip only
     if (mode == M_RADIANCE) {
       // ---- hit record: hit point, normal (per primitive), material ----
       V3 normal = mk(0, 0, 0);
@@ -742,14 +785,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           normal = mk(A.gnorm[4 * btri + 0], A.gnorm[4 * btri + 1], A.gnorm[4 * btri + 2]);
         }
       }
-      if (first) {
+      if (first_trip) {
         // kernel.hpp:55-56 (depth = +inf, normal = 0 on a miss)
-        first = false;
-        my_depth = best;
+        const size_t px_id = px_index();
         depth_out[px_id] = best;
         normal_out[3 * px_id + 0] = normal.x;
         normal_out[3 * px_id + 1] = normal.y;
         normal_out[3 * px_id + 2] = normal.z;
+        first_depth = best;
       }
       if (!was_hit) {
         out_rgb = mk(0.f, 0.f, 0.f);  // shading.hpp:119
@@ -769,14 +812,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       if (was_hit && best < light_dist) {
         // scenes without any transparency (the any-hit builds) need no material lookup here
         const float trans = ANYHIT ? 0.0f : A.mats[A.objs[bobj].mat].transparency;
-        intensity += (1.0f - trans);
-        if (intensity >= 1.0f) { shadow_fac = 1.0f; done_shadow = true; }
+        if (!ANYHIT) intensity += (1.0f - trans);
+        if (ANYHIT || intensity >= 1.0f) { shadow_fac = 1.0f; done_shadow = true; }
         else {
           min_t = (float)((double)best + 1e-3);  // last_hit + 1e-3 is a double add, shading.hpp:32
           done_shadow = false;                   // cast again (same ray)
         }
       } else {
-        shadow_fac = intensity;
+        shadow_fac = ANYHIT ? 0.0f : intensity;  // any-hit builds: the first occluder already ended the loop
         done_shadow = true;
       }
       if (done_shadow) {
@@ -868,6 +911,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       // return `out_rgb` to the suspended callers
       for (;;) {
         if (sp == 0) {
+          const size_t px_id = px_index();
           color_out[3 * px_id + 0] = out_rgb.x;
           color_out[3 * px_id + 1] = out_rgb.y;
           color_out[3 * px_id + 2] = out_rgb.z;
@@ -897,6 +941,16 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         }
       }
     }
+    if (first_trip) {
+      // max finite depth of the tile, reduced once here instead of carrying the depth to the end
+      uint32_t dbits = (__builtin_isfinite(first_depth) && first_depth > 0.f) ? __float_as_uint(first_depth) : 0u;
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)dbits, off);
+        dbits = o > dbits ? o : dbits;
+      }
+      wave_dbits = __builtin_amdgcn_readfirstlane(dbits);
+      first_trip = false;
+    }
     TSTAMP(t_cont1);
     TACC(2, t_loop1, t_cont1);
   }
@@ -910,6 +964,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
 #ifdef CTR_WAVELOG
   // diagnostic build only: lane 0 overwrites its pixel's normal with {start, end} of the wave (10 ns ticks)
   if (lane == 0 && in_image) {
+    const size_t px_id = px_index();
     const unsigned long long wl_end = __builtin_amdgcn_s_memrealtime();
     normal_out[px_id * 3 + 0] = __uint_as_float((uint32_t)wl_start);
     normal_out[px_id * 3 + 1] = __uint_as_float((uint32_t)wl_end);
@@ -921,14 +976,11 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   //  measured; one 128-byte shard per wave%CTR_SHARDS costs nothing measurable.  after_render
   //  then adds the shards into the caller's counters and clears them.)
   if (counters) {
-    unsigned long long c = n_casts;
-    uint32_t dbits = (in_image && __builtin_isfinite(my_depth) && my_depth > 0.f) ? __float_as_uint(my_depth) : 0u;
+    const unsigned long long c = n_casts;
+    const uint32_t dbits = wave_dbits;
     unsigned long long t = n_aabb_tris;
-    for (int off = 32; off > 0; off >>= 1) {
-      c += __shfl_xor(c, off);
-      uint32_t o = (uint32_t)__shfl_xor((int)dbits, off);
-      dbits = o > dbits ? o : dbits;
-      if (COUNT) t += __shfl_xor(t, off);
+    if (COUNT) {
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
     }
     unsigned long long *sh = counters + (size_t)(wave % CTR_SHARDS) * CTR_SHARD_WORDS;
     if (STATS && lane == 0) {
