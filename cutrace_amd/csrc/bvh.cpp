@@ -113,7 +113,7 @@ struct Builder {
     DNode nd;
     memset(&nd, 0, sizeof(nd));
     Box lb = bounds(begin, mid), rb = bounds(mid, end);
-    for (int a = 0; a < 3; a++) { nd.lmn[a] = lb.mn[a]; nd.lmx[a] = lb.mx[a]; nd.rmn[a] = rb.mn[a]; nd.rmx[a] = rb.mx[a]; }
+    for (int a = 0; a < 3; a++) { nd.mn[a][0] = lb.mn[a]; nd.mx[a][0] = lb.mx[a]; nd.mn[a][1] = rb.mn[a]; nd.mx[a][1] = rb.mx[a]; }
     nd.left = l;
     nd.right = r;
     nd.axis = (uint32_t)axis;

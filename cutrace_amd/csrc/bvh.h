@@ -26,8 +26,10 @@
 #define BVH_MAX_DEPTH 60  // the kernel keeps its stack in the 64 lanes of one VGPR
 
 struct DNode {
-  float lmn[3], lmx[3];  // left child's box
-  float rmn[3], rmx[3];  // right child's box
+  // [axis][child]: the two children's boxes interleaved, so that (left, right) of one coordinate is an
+  // aligned SGPR pair and one v_pk_fma_f32 evaluates a slab distance for BOTH boxes
+  float mn[3][2];        // min corners: mn[a][0] left child, mn[a][1] right child
+  float mx[3][2];        // max corners
   uint32_t left, right;  // child descriptors
   uint32_t axis;         // split axis (0,1,2): the child on the ray's near side is visited first
   uint32_t pad;

@@ -74,6 +74,34 @@ constexpr int WAVES_PER_WG = CTR_WAVES_PER_WG;
 constexpr int WG_THREADS = 64 * WAVES_PER_WG;
 
 struct V3 { float x, y, z; };
+typedef float float2_ __attribute__((ext_vector_type(2)));
+// d = s * v.{lo|hi} - k.{lo|hi} for both halves of the SGPR pair s: v_pk_fma_f32 with op_sel choosing
+// which half of the VGPR pairs v and k is broadcast (vsel/ksel: 0 = low, 1 = high), k negated
+#define PKFMA(d, s, v, vsel, k, ksel)                                                                          \
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #vsel "," #ksel "] op_sel_hi:[1," #vsel "," #ksel "] "          \
+      "neg_lo:[0,0,1] neg_hi:[0,0,1]"                                                                          \
+      : "=v"(d)                                                                                                \
+      : "s"(s), "v"(v), "v"(k))
+// max over the axes of min(t1, t2) / min over the axes of max(t1, t2); a NaN operand is ignored by
+// v_min/v_max (the other operand wins), i.e. that axis' constraint drops out as in the scalar version
+__device__ __forceinline__ float slab_lo(float ax, float bx, float ay, float by, float az, float bz) {
+  float x, y, z, r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(x) : "v"(ax), "v"(bx));
+  asm("v_min_f32 %0, %1, %2" : "=v"(y) : "v"(ay), "v"(by));
+  asm("v_min_f32 %0, %1, %2" : "=v"(z) : "v"(az), "v"(bz));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+__device__ __forceinline__ float slab_hi(float ax, float bx, float ay, float by, float az, float bz) {
+  float x, y, z, r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(ax), "v"(bx));
+  asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(ay), "v"(by));
+  asm("v_max_f32 %0, %1, %2" : "=v"(z) : "v"(az), "v"(bz));
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+// two adjacent floats of a wave-uniform record as one aligned SGPR pair
+__device__ __forceinline__ float2_ ldpair(const CADDR float (&p)[2]) { return *(const CADDR float2_ *)p; }
 
 // ---- inc/vector.hpp, same operation order -------------------------------------
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -390,15 +418,15 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           const V3 t_kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);
           while (t_pend != TL_NONE && !(t_pend & BVH_LEAF_FLAG)) {
             const CADDR DNode &N = A.nodes[A.tlas_begin + t_pend];
-            auto t_hits = [&](const auto &mn, const auto &mx) -> mask_t {
-              const float t1x = __builtin_fmaf(mn[0], ria.x, -t_ka.x), t2x = __builtin_fmaf(mx[0], ria.x, -t_kb.x);
-              const float t1y = __builtin_fmaf(mn[1], ria.y, -t_ka.y), t2y = __builtin_fmaf(mx[1], ria.y, -t_kb.y);
-              const float t1z = __builtin_fmaf(mn[2], ria.z, -t_ka.z), t2z = __builtin_fmaf(mx[2], ria.z, -t_kb.z);
+            auto t_hits = [&](int c) -> mask_t {
+              const float t1x = __builtin_fmaf(N.mn[0][c], ria.x, -t_ka.x), t2x = __builtin_fmaf(N.mx[0][c], ria.x, -t_kb.x);
+              const float t1y = __builtin_fmaf(N.mn[1][c], ria.y, -t_ka.y), t2y = __builtin_fmaf(N.mx[1][c], ria.y, -t_kb.y);
+              const float t1z = __builtin_fmaf(N.mn[2][c], ria.z, -t_ka.z), t2z = __builtin_fmaf(N.mx[2][c], ria.z, -t_kb.z);
               const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
               const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
               return lv_m & ~(FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, t_lim, FC_OGT));
             };
-            const bool hl = t_hits(N.lmn, N.lmx) != 0ull, hr = t_hits(N.rmn, N.rmx) != 0ull;
+            const bool hl = t_hits(0) != 0ull, hr = t_hits(1) != 0ull;
             const uint32_t dl = N.left, dr = N.right;
             if (hl && hr) {
               asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
@@ -642,15 +670,37 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             const uint32_t neg_bits = (__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31) |
                                       ((__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31) << 1) |
                                       ((__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31) << 2);
-            auto box_hits = [&](const auto &mn, const auto &mx) -> mask_t {
-              const float t1x = __builtin_fmaf(mn[0], ria.x, -ka.x), t2x = __builtin_fmaf(mx[0], ria.x, -kb.x);
-              const float t1y = __builtin_fmaf(mn[1], ria.y, -ka.y), t2y = __builtin_fmaf(mx[1], ria.y, -kb.y);
-              const float t1z = __builtin_fmaf(mn[2], ria.z, -ka.z), t2z = __builtin_fmaf(mx[2], ria.z, -kb.z);
+            // the nine per-ray constants of the box test, two to a register pair; PKFMA picks the half it
+            // needs with op_sel, so packing costs no extra registers
+            const float2_ c_rxy = {ria.x, ria.y}, c_rzk = {ria.z, ka.x}, c_kyz = {ka.y, ka.z};
+            const float2_ c_bxy = {kb.x, kb.y}, c_bz = {kb.z, 0.0f};
+            // both children's boxes at once: six v_pk_fma_f32 give the six slab distances of the left
+            // (.x) and the right (.y) box; reject only on a definite miss (NaN compares false -> entered)
+            auto box_hits2 = [&](const auto &N, mask_t &hl, mask_t &hr) {
+              float2_ t1x, t1y, t1z, t2x, t2y, t2z;
+              PKFMA(t1x, ldpair(N.mn[0]), c_rxy, 0, c_rzk, 1);
+              PKFMA(t1y, ldpair(N.mn[1]), c_rxy, 1, c_kyz, 0);
+              PKFMA(t1z, ldpair(N.mn[2]), c_rzk, 0, c_kyz, 1);
+              PKFMA(t2x, ldpair(N.mx[0]), c_rxy, 0, c_bxy, 0);
+              PKFMA(t2y, ldpair(N.mx[1]), c_rxy, 1, c_bxy, 1);
+              PKFMA(t2z, ldpair(N.mx[2]), c_rzk, 0, c_bz, 0);
+              // (min/max through asm as well: fminf/fmaxf on asm results would first re-canonicalise
+              //  every operand, 12 extra VALU ops per node)
+              const float lo_l = slab_lo(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x);
+              const float hi_l = slab_hi(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x);
+              const float lo_r = slab_lo(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y);
+              const float hi_r = slab_hi(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y);
+              hl = bb_m & ~(FCMP(lo_l, hi_l, FC_OGT) | FCMP(hi_l, min_t, FC_OLT) | FCMP(lo_l, lim, FC_OGT));
+              hr = bb_m & ~(FCMP(lo_r, hi_r, FC_OGT) | FCMP(hi_r, min_t, FC_OLT) | FCMP(lo_r, lim, FC_OGT));
+            };
+            // the same test with per-lane node data (vector-memory variant)
+            auto box_hits_v = [&](const DNode &Nv, int c) -> mask_t {
+              const float t1x = __builtin_fmaf(Nv.mn[0][c], ria.x, -ka.x), t2x = __builtin_fmaf(Nv.mx[0][c], ria.x, -kb.x);
+              const float t1y = __builtin_fmaf(Nv.mn[1][c], ria.y, -ka.y), t2y = __builtin_fmaf(Nv.mx[1][c], ria.y, -kb.y);
+              const float t1z = __builtin_fmaf(Nv.mn[2][c], ria.z, -ka.z), t2z = __builtin_fmaf(Nv.mx[2][c], ria.z, -kb.z);
               const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
               const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-              // reject only on a definite miss (NaN compares false -> the box is entered)
-              const mask_t miss = FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, lim, FC_OGT);
-              return bb_m & ~miss;
+              return bb_m & ~(FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, lim, FC_OGT));
             };
             auto leaf = [&](uint32_t desc, mask_t lanes) {
               const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
@@ -679,15 +729,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
                   uint32_t cv = O.node_begin + cur;
                   HIDE_UNIFORM(cv);
                   const DNode Nv = A.nodes_g[cv];
-                  hl = box_hits(Nv.lmn, Nv.lmx);
-                  hr = box_hits(Nv.rmn, Nv.rmx);
+                  hl = box_hits_v(Nv, 0);
+                  hr = box_hits_v(Nv, 1);
                   n_left = __builtin_amdgcn_readfirstlane(Nv.left);
                   n_right = __builtin_amdgcn_readfirstlane(Nv.right);
                   n_axis = __builtin_amdgcn_readfirstlane(Nv.axis);
                 } else {
                   const CADDR DNode &N = nodes[cur];
-                  hl = box_hits(N.lmn, N.lmx);
-                  hr = box_hits(N.rmn, N.rmx);
+                  box_hits2(N, hl, hr);
                   n_left = N.left; n_right = N.right; n_axis = N.axis;
                 }
                 // near child first
