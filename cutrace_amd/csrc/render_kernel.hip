@@ -316,17 +316,15 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     // ---- planes: plane::intersect, default_schema.hpp:189-201, all in lane masks ----
     {
       mask_t live_m = BALLOT(live);
-      for (uint32_t p = 0; p < A.n_planes; ++p) {
-        const CADDR DPlane &P = A.planes[p];
-        const V3 pp = mk(P.px, P.py, P.pz), n = mk(P.nx, P.ny, P.nz);
-        const float num = vdot(vsub(pp, ro), n), den = vdot(rd, n);
+      // one plane against the live lanes; returns false when every lane has retired (any-hit)
+      auto plane_test = [&](const auto &P, float num, float den) -> bool {
         // The IEEE division is only worth doing where the quotient can matter: skip it (for the
         // whole wave) when a 1-ulp reciprocal already proves t0 < min_t or t0 >= the current bound.
         const float ta = num * __builtin_amdgcn_rcpf(den);
         const float mrg = fabsf(ta) * 0x1p-18f + 1e-30f;
         const float lim_hi = anyhit_cast ? light_dist : best;
         const mask_t need_m = live_m & ~(FCMP(ta + mrg, min_t, FC_OLT) | FCMP(ta - mrg, lim_hi, FC_OGT));  // NaN/inf -> needed
-        if (need_m == 0ull) continue;
+        if (need_m == 0ull) return true;
         bool retire = false;
         if (INVB(need_m)) {
           const float t0 = num / den;
@@ -340,7 +338,22 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         }
         if (ANYHIT) {
           live_m &= ~BALLOT(retire);
-          if (live_m == 0ull) break;
+          if (live_m == 0ull) return false;
+        }
+        return true;
+      };
+      // two planes per trip of the loop: the second record is requested while the first is being
+      // worked on (scalar-load round trips, not arithmetic, are most of a wave's life)
+      for (uint32_t p = 0; p < A.n_planes; p += 2) {
+        const bool two = p + 1 < A.n_planes;
+        const CADDR DPlane &P0 = A.planes[p];
+        const CADDR DPlane &P1 = A.planes[two ? p + 1 : p];
+        const V3 n0 = mk(P0.nx, P0.ny, P0.nz), n1 = mk(P1.nx, P1.ny, P1.nz);
+        const float num0 = vdot(vsub(mk(P0.px, P0.py, P0.pz), ro), n0), den0 = vdot(rd, n0);
+        const float num1 = vdot(vsub(mk(P1.px, P1.py, P1.pz), ro), n1), den1 = vdot(rd, n1);
+        if (!plane_test(P0, num0, den0)) break;
+        if (two) {
+          if (!plane_test(P1, num1, den1)) break;
         }
       }
       if (ANYHIT) live = INVB(live_m);

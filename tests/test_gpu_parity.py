@@ -229,7 +229,7 @@ def test_bad_arguments_fail_loudly(gpu):
         ds.render(rows=(3, 20, 8, 0, 2))  # row_begin not block-aligned with n_parts > 1
 
 
-def _random_scene(seed, w=72, h=48):
+def _random_scene(seed, w=72, h=48, opaque_mesh=False):
     """Seeded random scene mixing every primitive, light and material feature (incl. reflect +
     transparency on the same material, coincident planes, a mesh and stand-alone triangles)."""
     import json
@@ -242,7 +242,7 @@ def _random_scene(seed, w=72, h=48):
     for _ in range(int(rng.randint(2, 6))):
         mats.append({"type": "solid", "color": v(0.05, 1.0), "specular": float(rng.uniform(0, 1)),
                      "reflect": float(rng.choice([0.0, 0.0, 0.3, 0.9])), "phong": float(rng.choice([0.0, 1.0, 20.0, 300.0])),
-                     "transparency": float(rng.choice([0.0, 0.0, 0.0, 0.5]))})
+                     "transparency": 0.0 if opaque_mesh else float(rng.choice([0.0, 0.0, 0.0, 0.5]))})
     nm = len(mats)
     objs = []
     for _ in range(int(rng.randint(1, 5))):
@@ -254,7 +254,7 @@ def _random_scene(seed, w=72, h=48):
     if rng.rand() < 0.5:
         objs.append(dict(floor, material=int(rng.randint(nm))))  # coincident plane: exact tie on t
     objs.append({"type": "plane", "point": [0, 0, -3], "normal": [0, 0, 1], "material": int(rng.randint(nm))})
-    if rng.rand() < 0.7:
+    if opaque_mesh or rng.rand() < 0.7:
         objs.insert(int(rng.randint(len(objs) + 1)), {"type": "mesh", "file": "scene/skull.stl", "material": int(rng.randint(nm))})
     lights = [{"type": "sun", "direction": v(-1, 1), "color": v(0.2, 1)}]
     for _ in range(int(rng.randint(0, 3))):
@@ -276,6 +276,25 @@ def test_seeded_random_scenes(gpu, seed):
         r = ds.render(bounces=b)
         assert_parity(r, o, what=f"random scene seed {seed} variant {variant}")
         assert r["ray_count"] == o["ray_count"]
+
+
+@pytest.mark.parametrize("seed", list(range(100, 108)))
+def test_seeded_random_opaque_mesh_scenes(gpu, seed):
+    """All-opaque scenes with a mesh: the any-hit shadow path incl. the prefilter's decisive accept and
+    ray-parameter rejects (render_kernel.hip, prefilter stage 2) against the oracle and, bitwise, against
+    the kernel with every shortcut switched off."""
+    s = gpu.HostScene.parse(_random_scene(seed, w=96, h=64, opaque_mesh=True))
+    assert s.ok
+    b = [1, 2, 3, 5][seed % 4]
+    o = oracle.oracle_render(s, bounces=b, threads=os.cpu_count() or 4)
+    ds = gpu.DeviceScene(s)
+    r = ds.render(bounces=b)
+    assert_parity(r, o, what=f"opaque mesh scene seed {seed}")
+    assert r["ray_count"] == o["ray_count"]
+    ds.set_variant(gpu.VAR_NO_CLUSTER | gpu.VAR_NO_PREFILTER | gpu.VAR_NO_ANYHIT)
+    plain = ds.render(bounces=b)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(r[k], plain[k]), (k, seed)
 
 
 def test_tile_scheduling_feedback_never_changes_results(gpu):
