@@ -244,7 +244,9 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   // in two VGPRs for the whole wave: registers, not instructions, are what this kernel is short of.
   const uint32_t tile_px0 = ty * TH * w + tx * TW;  // wave-uniform
   auto px_index = [&]() -> size_t {
-    return (size_t)frame * A.frame_stride_px + (size_t)(tile_px0 + (lane / TW) * w + (lane % TW));
+    uint32_t l = lane;
+    asm volatile("" : "+v"(l));  // recompute here: hoisted out of the loop the addresses would be spilled to scratch
+    return (size_t)frame * A.frame_stride_px + (size_t)(tile_px0 + (l / TW) * w + (l % TW));
   };
 
   // ---- cam::get_ray, default_schema.hpp:376-386 ----

@@ -196,7 +196,7 @@ int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ct
 #define CTR_VAR_NO_PREFILTER 2u   /* run the exact Cramer test on every triangle */
 #define CTR_VAR_NO_ANYHIT 4u      /* never use the any-hit shadow early-out */
 #define CTR_VAR_NO_CLUSTER 8u     /* walk meshes linearly instead of through their BVH */
-#define CTR_VAR_EXACT_POW 32u     /* specular pow() in f64 (<=1 ulp of glibc powf) instead of f32 exp2/log2 */
+#define CTR_VAR_EXACT_POW 32u     /* exact specular term: pow() in f64 (<=1 ulp of glibc powf), IEEE half-vector normalisation */
 #define CTR_VAR_VMEM 64u          /* mesh data through the vector memory path (comparison only; scalar is faster) */
 #define CTR_VAR_SMEM 128u         /* force the scalar-cache path (the default) */
 #define CTR_VAR_STATS 16u         /* diagnostic build: print wave-level work counters to stderr */
