@@ -23,19 +23,24 @@
 //    unit), not per-lane booleans.
 //  * per mesh: the reference's AABB test decided with 1-ulp reciprocals except on borderline lanes;
 //    a BVH (inner nodes hold both children's boxes, wave-uniform stack in the lanes of one VGPR)
-//    walked by the whole wave; per triangle a conservative FMA prefilter (31 VALU ops) for the
-//    whole wave, then the reference's exact Cramer/determinant test (default_schema.hpp:57-78) in
-//    the reference's operation order for surviving lanes, its three IEEE divisions performed only
-//    where a 1-ulp reciprocal cannot decide.  All of these can only produce false positives, so
-//    results are identical to the reference's linear walk (ties broken by file order).
+//    walked by the whole wave, both child boxes per node tested with packed FMAs; per triangle a
+//    conservative FMA prefilter for the whole wave (barycentrics, then — only if a lane survives —
+//    the ray parameter), then the reference's exact Cramer/determinant test
+//    (default_schema.hpp:57-78) in the reference's operation order for surviving lanes, its three
+//    IEEE divisions performed only where a 1-ulp reciprocal cannot decide.  Every shortcut acts
+//    only on "certainly" (margins above the rounding of both evaluations), so results are identical
+//    to the reference's linear walk (ties broken by file order).
 //  * shadow rays stop at the first occluder when no material is transparent.
 //  * the duplicated primary cast (kernel.hpp:52 + shading.hpp:123) is done once.
+//  * tiles are dispatched expensive-first from the costs the previous launch recorded (after_render),
+//    which removes the tail of slow waves at the end of a frame.
 //
 // Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE correctly rounded on gfx950,
 // so every geometric quantity (depth, hit, normal, which object is hit) is bit-identical to the
-// host-compiled reference.  The specular pow() is exp2(e*log2(x)) in f32 by default (<= 1e-6
-// relative where it matters) or f64 pow rounded once (CTR_VAR_EXACT_POW, bit-identical to glibc
-// powf on every tested pixel); it only feeds the colour.  Texture coordinates (atan2/asin, uv_for)
+// host-compiled reference.  The specular term — the half vector's normalisation and pow() — uses
+// v_rsq_f32 and exp2(e*log2(x)) in f32 by default (colour within 3e-6 of the reference) or IEEE
+// sqrt/division and f64 pow rounded once (CTR_VAR_EXACT_POW, bit-identical to glibc powf on every
+// tested pixel); it only feeds the colour.  Texture coordinates (atan2/asin, uv_for)
 // are never produced: the only material type ignores them (default_schema.hpp:326-340).
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -665,9 +670,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             // children's boxes, so a child no lane touches is never loaded and leaves cost no node
             // load.  Pending inner children wait on a wave-uniform stack kept in the lanes of ONE
             // VGPR (v_writelane / v_readlane); the child on the near side of the split axis goes
-            // first.  The box test is conservative: boxes are widened by m = 2^-15 x (largest
-            // |coordinate difference| between the ray origin and the mesh), applied in t-space as a
-            // slack of 2*m*max|1/dir|; a NaN enters the box.
+            // first.
             // The box test is conservative: every box is widened in WORLD space by
             //   m = 2^-14 x (largest |coordinate difference| between the ray origin and the mesh box)
             // per axis ((mn - m - o)/d and (mx + m - o)/d, folded into the two FMA constants below), far
