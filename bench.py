@@ -70,12 +70,30 @@ def cpu_baseline(ca, host_scene, bounces, div):
     t0 = time.perf_counter()
     r = fn(host_scene, bounces=bounces, rows=rows, threads=threads, hit_ids=False)
     dt = time.perf_counter() - t0
+    # one thread on a 1/threads-th of that sample (1 thread and all hardware threads)
+    rows1 = (0, h, 8, 0, div * threads)
+    t1 = time.perf_counter()
+    r1 = fn(host_scene, bounces=bounces, rows=rows1, threads=1, hit_ids=False)
+    dt1 = time.perf_counter() - t1
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
         "value": r["ray_count"] / dt / 1e6, "unit": "Mrays/s", "cores": threads,
         "kind": "reference" if use_ref else "port",
         "sample": f"every {div}th 8-row block of the {w}x{h} frame ({r['depth'].shape[0]} rows, "
                   f"{r['ray_count']} rays) in {dt:.2f} s",
         "seconds": dt,
+        "cpu_model": model,
+        "one_thread": {"value": r1["ray_count"] / dt1 / 1e6 if dt1 > 0 else 0.0, "unit": "Mrays/s",
+                       "sample": f"every {div * threads}th 8-row block ({r1['depth'].shape[0]} rows, "
+                                 f"{r1['ray_count']} rays) in {dt1:.2f} s"},
     }
 
 
