@@ -15,7 +15,7 @@ import oracle
 
 from tests.conftest import load_scene
 from tests.test_oracle_golden import GOLD, parse
-from tests.util import assert_parity, same_bits
+from tests.util import assert_parity, same_bits, mesh_scene as _mesh_scene, corner_meshes
 
 pytestmark = pytest.mark.gpu
 
@@ -349,3 +349,39 @@ def test_tile_scheduling_feedback_never_changes_results(gpu):
             assert same_bits(d[f, :len(yf)], ref["depth"][yf]), f
             assert same_bits(c[f, :len(yf)], ref["color"][yf]), f
             assert (d[f, len(yf):] == -1.0).all()   # padding rows untouched
+
+
+def _check_all_ways(gpu, s, what, bounces=3, fudge=1e-3):
+    o = oracle.oracle_render(s, bounces=bounces, fudge=fudge, threads=os.cpu_count() or 4)
+    ds = gpu.DeviceScene(s)
+    r = ds.render(bounces=bounces, fudge=fudge)
+    assert_parity(r, o, what=what)
+    assert r["ray_count"] == o["ray_count"]
+    ds.set_variant(gpu.VAR_NO_CLUSTER | gpu.VAR_NO_PREFILTER | gpu.VAR_NO_ANYHIT)
+    plain = ds.render(bounces=bounces, fudge=fudge)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(r[k], plain[k]), (what, k)
+    return r
+
+
+def test_mesh_corner_cases(gpu, tmp_path):
+    """Meshes the shortcuts could trip over: coincident duplicate triangles (exact ties on t -> file
+    order), zero-area triangles (alpha == 0: the reference divides by zero), a single-triangle mesh (BVH
+    root is a leaf), an empty mesh, triangles meeting edge-on under the camera, far-away coordinates;
+    image sizes 1x1, 8x8 and 9x9; fudge 0 and negative (prefilter stage 2 must switch itself off)."""
+    quad, dup, degenerate, fan, far = corner_meshes()
+    cases = [("duplicates", dup, 64, 40), ("degenerate", degenerate, 64, 40), ("single", quad[:1], 40, 24),
+             ("fan", fan, 72, 48), ("1x1", fan, 1, 1), ("8x8", fan, 8, 8), ("9x9", dup, 9, 9)]
+    for name, tris, w, h in cases:
+        s = gpu.HostScene.parse(_mesh_scene(str(tmp_path / f"{name}.stl"), w, h, tris))
+        assert s.ok, name
+        _check_all_ways(gpu, s, name)
+    # far-away mesh next to a near one: margins scale with the coordinates
+    s = gpu.HostScene.parse(_mesh_scene(str(tmp_path / "far.stl"), 64, 40, far,
+                                        extra_objects=[{"type": "mesh", "file": str(tmp_path / "fan.stl"), "material": 1}]))
+    assert s.ok
+    _check_all_ways(gpu, s, "far + near mesh")
+    # fudge 0 / negative: self-intersections at t ~ 0 become valid hits in the reference
+    s = gpu.HostScene.parse(_mesh_scene(str(tmp_path / "fan.stl"), 48, 32, fan))
+    for fudge in (0.0, -0.5, 1e-6):
+        _check_all_ways(gpu, s, f"fudge {fudge}", bounces=2, fudge=fudge)

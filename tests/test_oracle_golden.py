@@ -123,3 +123,23 @@ def test_look_at_matches(ca):
         R.ref_look_at(C.byref(c), eye, up, look)
         for f in ("pos", "up", "forward", "right"):
             assert getattr(a, f).tup() == getattr(c, f).tup()
+
+
+def test_oracle_matches_reference_build_on_corner_meshes(ca, tmp_path):
+    """The restatement against the reference's own headers (oracle/_ref) where the shortcuts of the HIP
+    path are most exposed: duplicate and zero-area triangles, fudge 0 and negative."""
+    import oracle
+    from tests.util import mesh_scene, corner_meshes
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    quad, dup, degenerate, fan, far = corner_meshes()
+    for name, tris in (("dup", dup), ("degenerate", degenerate), ("fan", fan), ("far", far)):
+        s = ca.HostScene.parse(mesh_scene(str(tmp_path / f"{name}.stl"), 48, 32, tris))
+        assert s.ok
+        for fudge in (1e-3, 0.0, -0.5):
+            o = oracle.oracle_render(s, bounces=3, fudge=fudge, threads=os.cpu_count() or 2)
+            r = oracle.ref_render(s, bounces=3, fudge=fudge, threads=os.cpu_count() or 2)
+            for k in ("depth", "normal", "color", "hit_id"):
+                assert np.array_equal(o[k].view(np.uint32) if o[k].dtype == np.float32 else o[k],
+                                      r[k].view(np.uint32) if r[k].dtype == np.float32 else r[k]), (name, fudge, k)
+            assert o["ray_count"] == r["ray_count"]

@@ -44,3 +44,29 @@ def assert_parity(got, want, what="", color_tol=TOL):
     assert nr["not_bitexact"] == 0, msg
     assert cr["over_tol"] == 0, msg
     return dict(depth=dr, normal=nr, color=cr)
+
+
+def mesh_scene(stl_path, w, h, tris, extra_objects=(), fudge_note=""):
+    import json
+    from cutrace_amd import scenes
+    scenes.write_stl(stl_path, np.asarray(tris, np.float32).reshape(-1, 3, 3))
+    mats = [{"type": "solid", "color": [0.8, 0.6, 0.3], "specular": 0.4, "reflect": 0.3, "phong": 40},
+            {"type": "solid", "color": [0.3, 0.5, 0.9], "specular": 0.2, "reflect": 0.0, "phong": 10}]
+    objs = [{"type": "mesh", "file": stl_path, "material": 0},
+            {"type": "plane", "point": [0, -1.0, 0], "normal": [0, 1, 0], "material": 1}] + list(extra_objects)
+    lights = [{"type": "point", "point": [1.5, 2.5, 2.0], "color": [0.8, 0.8, 0.8]},
+              {"type": "sun", "direction": [-0.3, -1.0, -0.2], "color": [0.4, 0.4, 0.4]}]
+    cam = {"eye": [0.3, 0.8, 4.0], "up": [0, 1, 0], "look": [-0.05, -0.15, -1.0], "near_plane": 0.1, "far_plane": 100.0,
+           "width": w, "height": h, "ambient": 0.1}
+    return json.dumps({"camera": cam, "lights": lights, "materials": mats, "objects": objs})
+
+
+def corner_meshes():
+    """Triangle lists for the mesh corner-case tests: quad, duplicates, degenerate, fan, far."""
+    quad = [[[-1, -1, 0], [1, -1, 0], [1, 1, 0]], [[-1, -1, 0], [1, 1, 0], [-1, 1, 0]]]
+    dup = quad + quad + [[[-1, -1, 0.5], [1, -1, 0.5], [0, 1, 0.5]]] * 3          # duplicates and triplicates
+    degenerate = quad + [[[0, 0, 1], [0, 0, 1], [0, 0, 1]], [[0, 0, 1], [1, 1, 1], [2, 2, 1]]]  # point, collinear
+    fan = [[[0, 0, 0.3], [float(np.cos(a)), float(np.sin(a)), 0.0], [float(np.cos(a + 0.7)), float(np.sin(a + 0.7)), 0.0]]
+           for a in np.arange(0, 6.28, 0.7)]
+    far = (np.asarray(quad, np.float32) * 500.0 + np.float32([3000, 0, -9000])).tolist()
+    return quad, dup, degenerate, fan, far
