@@ -48,6 +48,8 @@ def parse_args():
     p.add_argument("--skip-probe", action="store_true",
                    help="skip the untimed image-order launches after the timed region (profiling runs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--check", action="store_true",
+                   help="rank 0 compares every gathered frame bitwise with a single-process render")
     p.add_argument("--cpu-sample-div", type=int, default=0, help="CPU baseline renders 1/div of the row blocks (0=auto)")
     p.add_argument("--of", type=int, default=0, help="diagnostic: time the tiled batch render of one rank of N (no gather)")
     p.add_argument("--as-rank", type=int, default=0)
@@ -112,11 +114,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # Rehearsal on a one-GPU box (never the measured configuration): CUTRACE_BENCH_SHARE_GPU=1 puts every
+    # rank on device 0 and CUTRACE_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one GPU.
+    if os.environ.get("CUTRACE_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("CUTRACE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     hs = ca.HostScene.load(args.scene)
     assert hs.ok, "scene failed to load"
@@ -212,6 +222,17 @@ def main():
         dt_max, rays_step, kern_avg = float(tmax[0]), float(tsum[1]), float(tsum[2]) / world
     else:
         dt_max, rays_step, kern_avg = dt, float(rays_rank_step), float(t[2])
+
+    if args.check and rank == 0:
+        import numpy as np
+        ref = ca.DeviceScene(hs, device=local_rank)
+        ref.set_variant(ca.VAR_NO_REORDER)
+        want = ref.render(bounces=args.bounces)
+        for f in range(frames):
+            for k in ("depth", "color", "normal"):
+                got = tiler.final[k][f].cpu().numpy()
+                assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), f"--check: frame {f} {k} differs"
+        print(f"check: {frames} gathered frame(s) bitwise equal to the single-process render", file=sys.stderr, flush=True)
 
     if rank == 0:
         total_rays = rays_step * args.steps
