@@ -145,3 +145,30 @@ def test_jpeg_writer_produces_a_decodable_image(ca, tmp_path):
     im = np.asarray(Image.open(path).convert("RGB")).astype(np.int32)
     assert im.shape == (h, w, 3)
     assert np.abs(im - rgb.astype(np.int32)).mean() < 3.0
+
+
+def test_dump_scene_text_is_the_reference_format(ca, capfd):
+    """gpu::dump_scene (inc/kernel.hpp:150-166): ' -> Have %-4llu objects:' / '  -> Object   #%-4llu has type #%-2llu'
+    with the reference's variant indices (triangle 0, mesh 1, plane 2, sphere 3; sun 0, point 1; solid 0)."""
+    from cutrace_amd import _lib
+    from tests.conftest import load_scene
+    s = load_scene(ca, "sphere_plane")
+    capfd.readouterr()
+    _lib.host_lib().ctr_dump_scene(s.desc)
+    out = capfd.readouterr().out.splitlines()
+    d = s.desc.contents
+    assert out[0] == " -> Have %-4d objects:" % d.n_objects
+    want_types = {"sphere": 3, "plane": 2}
+    import json
+    js = json.load(open("scene/sphere_plane.json"))
+    for i, o in enumerate(js["objects"]):
+        assert out[1 + i] == "  -> Object   #%-4d has type #%-2d" % (i, want_types[o["type"]])
+    k = 1 + len(js["objects"])
+    assert out[k] == " -> Have %-4d lights:" % len(js["lights"])
+    for i, l in enumerate(js["lights"]):
+        assert out[k + 1 + i] == "  -> Light    #%-4d has type #%-2d" % (i, {"sun": 0, "point": 1}[l["type"]])
+    k += 1 + len(js["lights"])
+    assert out[k] == " -> Have %-4d materials:" % len(js["materials"])
+    for i in range(len(js["materials"])):
+        assert out[k + 1 + i] == "  -> Material #%-4d has type #%-2d" % (i, 0)
+    assert len(out) == k + 1 + len(js["materials"])
