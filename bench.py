@@ -242,6 +242,7 @@ def main():
         alg_bytes, alg_rays = alg_bytes * frames, alg_rays * frames  # one launch renders `frames` frames
         achieved = alg_bytes / (kern_avg * 1e-3) / 1e9 if kern_avg > 0 else 0.0
         traffic = None
+        valu_insts = None
         tj = args.traffic_json or os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and os.path.exists(tj):
             # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
@@ -249,12 +250,17 @@ def main():
             t_ = json.load(open(tj))
             if t_.get("workload") == f"{os.path.basename(args.scene)}@{w}x{h}b{args.bounces}":
                 traffic = t_.get("hbm_bytes_per_launch")
+                valu_insts = t_.get("valu_insts_per_launch")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "render_kernel",
                 "kernel_ms_avg": kern_avg, "algorithmic_bytes_per_launch": alg_bytes,
                 "rays_per_launch": alg_rays,
                 "note": "VALU-bound kernel: scene is cache-resident, algorithmic bytes are what the "
                         "reference's flat traversal streams per ray, not HBM traffic"}
+        if valu_insts and kern_avg > 0:
+            # the bound that actually binds: wave-level VALU instructions (PMC SQ_INSTS_VALU of the same
+            # workload) x 4 issue cycles over 1024 SIMDs x kernel time at the 2.4 GHz engine clock
+            roof["valu_issue_busy"] = valu_insts * 4.0 / (1024.0 * kern_avg * 1e-3 * 2.4e9)
         out = {
             "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

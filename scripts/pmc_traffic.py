@@ -18,6 +18,8 @@ for line in open(summary):
 fetch_kib, write_kib = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 res = {"workload": workload, "kernel": kern, "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
        "fetch_correction": 2.0, "hbm_bytes_per_launch": int((2.0 * fetch_kib + write_kib) * 1024),
+       "valu_insts_per_launch": vals.get("SQ_INSTS_VALU"), "salu_insts_per_launch": vals.get("SQ_INSTS_SALU"),
+       "smem_insts_per_launch": vals.get("SQ_INSTS_SMEM"),
        "source": summary}
 json.dump(res, open(out, "w"), indent=1)
 print(res)
