@@ -205,7 +205,9 @@ int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ct
  * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles
  * first, which removes the tail of slow waves at the end of a frame.  Results do not depend on the
  * order.  The first launch of a shape, and every launch under CTR_VAR_NO_REORDER, uses image order.
- * Consequence: launches on ONE scene handle must be ordered by the caller (one stream at a time). */
+ * Consequence: launches on ONE scene handle must be ordered by the caller (one stream at a time).
+ * The first launch of a shape allocates the (small) cost/order buffers with hipMalloc: make that
+ * launch before capturing ctr_render_device into a HIP graph, or capture under CTR_VAR_NO_REORDER. */
 int ctr_set_variant(ctr_scene *scene, uint32_t variant_bits);
 
 /* Algorithmic bytes: 56·n_objects per ray_cast + 48·n_tri for
