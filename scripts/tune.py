@@ -16,6 +16,12 @@ for name, b in (("bunny", 5), ("mirror", 8), ("sphere_plane", 5)):
     ds.render(bounces=b)
     t = [ds.render(bounces=b)["kernel_ms"] for _ in range(7)]
     out[name] = round(statistics.median(t), 3)
+import tempfile
+from cutrace_amd import scenes
+s = ca.HostScene.load(scenes.make_dense_bunny(tempfile.mkdtemp(), 2))
+ds = ca.DeviceScene(s)
+ds.render()
+out["dense16k"] = round(statistics.median([ds.render()["kernel_ms"] for _ in range(7)]), 3)
 print(json.dumps(out))
 ''' % ROOT
 
