@@ -366,6 +366,11 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       if (ANYHIT) live = INVB(live_m);
     }
     // ---- spheres and stand-alone triangles, scene order ----
+    // sphere::intersect normalises the direction first (default_schema.hpp:227): once per cast (at the
+    // first sphere the cast meets), not once per sphere
+    V3 sph_d = mk(0, 0, 0);
+    float sph_dd = 0.f;
+    bool sph_have = false;  // wave-uniform
     for (uint32_t oi = 0; oi < A.n_oloop; ++oi) {
       if (ANYHIT) {
         if (BALLOT(live) == 0ull) break;
@@ -378,19 +383,29 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       int ctri = -1;
       if (type == CTR_OBJ_SPHERE) {
         // ---- sphere::intersect, default_schema.hpp:226-251 ----
-        float sx_ = rd.x, sy_ = rd.y, sz_ = rd.z;
-        PIN3(sx_, sy_, sz_);  // do not speculate the normalisation into scenes without spheres
-        const V3 d = vnormalized(mk(sx_, sy_, sz_)), c = mk(O.f[0], O.f[1], O.f[2]);
+        if (!sph_have) {
+          float sx_ = rd.x, sy_ = rd.y, sz_ = rd.z;
+          PIN3(sx_, sy_, sz_);  // keeps the normalisation out of scenes without spheres (no hoisting)
+          sph_d = vnormalized(mk(sx_, sy_, sz_));
+          sph_dd = vdot(sph_d, sph_d);
+          sph_have = true;
+        }
+        const V3 d = sph_d, c = mk(O.f[0], O.f[1], O.f[2]);
         const float R = O.f[3];
         const V3 ec = vsub(ro, c);
         const float dec = -vdot(d, ec);
-        const float dd = vdot(d, d);
+        const float dd = sph_dd;
         const float sub = dec * dec - dd * (vdot(ec, ec) - R * R);
-        const float sq = sqrtf(sub);
-        const float t0 = (dec - sq) / dd, t1 = (dec + sq) / dd;
-        const bool t0v = __builtin_isfinite(t0) && min_t <= t0, t1v = __builtin_isfinite(t1) && min_t <= t1;
-        ok = t0v || t1v;
-        cand = (t0v && t1v) ? smin(t0, t1) : (t0v ? t0 : t1);
+        // sub < 0: sqrt gives NaN, both roots are NaN, the sphere is missed (that IS how the reference
+        // signals a miss) — so the square root and the two divisions run only if some live lane has
+        // sub >= 0 or NaN (the exact reference value of sub decides, no margin involved)
+        if (BALLOT(live && !(sub < 0.0f)) != 0ull) {
+          const float sq = sqrtf(sub);
+          const float t0 = (dec - sq) / dd, t1 = (dec + sq) / dd;
+          const bool t0v = __builtin_isfinite(t0) && min_t <= t0, t1v = __builtin_isfinite(t1) && min_t <= t1;
+          ok = t0v || t1v;
+          cand = (t0v && t1v) ? smin(t0, t1) : (t0v ? t0 : t1);
+        }
       } else {
         // ---- stand-alone triangle, default_schema.hpp:57-78 ----
         const CADDR DTri &T = A.tris[O.tri_begin];
