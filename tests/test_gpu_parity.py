@@ -385,3 +385,19 @@ def test_mesh_corner_cases(gpu, tmp_path):
     s = gpu.HostScene.parse(_mesh_scene(str(tmp_path / "fan.stl"), 48, 32, fan))
     for fudge in (0.0, -0.5, 1e-6):
         _check_all_ways(gpu, s, f"fudge {fudge}", bounces=2, fudge=fudge)
+
+
+@pytest.mark.parametrize("w,h", [(1001, 777), (2048, 1536), (8, 8), (1, 4000)])
+def test_tile_order_is_a_permutation_at_odd_and_large_sizes(gpu, w, h):
+    """The counting sort behind the tile order (after_render) at wave counts that are not multiples of its
+    block size, at one wave, and at ~49k waves: every launch must still write every pixel exactly once."""
+    s = load_scene(gpu, "sphere_plane", w, h)
+    ref_ds = gpu.DeviceScene(s)
+    ref_ds.set_variant(gpu.VAR_NO_REORDER)
+    ref = ref_ds.render(bounces=3)
+    ds = gpu.DeviceScene(s)
+    for i in range(3):
+        r = ds.render(bounces=3)
+        for k in ("depth", "normal", "color"):
+            assert same_bits(r[k], ref[k]), (k, i, w, h)
+        assert r["ray_count"] == ref["ray_count"]
