@@ -152,10 +152,18 @@ def test_bench_multi_rank_path_on_one_gpu(ca):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--width", "480", "--height", "272", "--check"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "check: 2 gathered frame(s) bitwise equal" in r.stderr
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    import signal
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)  # own process group: a hang must not leave ranks behind
+    try:
+        out_s, err_s = p.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        p.communicate()
+        raise AssertionError("multi-rank rehearsal timed out")
+    assert p.returncode == 0, err_s[-2000:]
+    assert "check: 2 gathered frame(s) bitwise equal" in err_s
+    line = [l for l in out_s.splitlines() if l.startswith("{")][-1]
     import json
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["frames_per_step"] == 2
