@@ -100,7 +100,7 @@ struct ctr_scene {
   DObj *d_meshes = nullptr;
   uint32_t n_mesh = 0, tlas_root = BVH_LEAF_FLAG, tlas_begin = 0;
   float tl_mn[3] = {0, 0, 0}, tl_mx[3] = {0, 0, 0};
-  DPlane *d_planes = nullptr;
+  DPlanePair *d_planes = nullptr;
   uint32_t n_oloop = 0, n_planes = 0;
   DTri *d_tris = nullptr;
   DNode *d_nodes = nullptr;
@@ -392,10 +392,24 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     }
   }
   std::vector<DObj> oloop, meshes_in, meshes;
-  std::vector<DPlane> planes;
+  std::vector<DPlanePair> planes;
+  uint32_t n_planes = 0;
   for (const DObj &O : objs) {
-    if (O.type == CTR_OBJ_PLANE) planes.push_back(DPlane{O.f[0], O.f[1], O.f[2], O.f[3], O.f[4], O.f[5], O.index, O.mat});
-    else if (O.type == CTR_OBJ_MESH) { if (O.tri_count) meshes_in.push_back(O); }  // an empty mesh is never hit
+    if (O.type == CTR_OBJ_PLANE) {
+      if (n_planes % 2 == 0) {
+        DPlanePair pr;  // second slot starts as a copy of the first and is marked as padding
+        for (int a = 0; a < 3; a++) { pr.p[a][0] = pr.p[a][1] = O.f[a]; pr.n[a][0] = pr.n[a][1] = O.f[3 + a]; }
+        pr.index[0] = O.index;
+        pr.index[1] = CTR_PLANE_PAD;
+        pr.pad[0] = pr.pad[1] = 0;
+        planes.push_back(pr);
+      } else {
+        DPlanePair &pr = planes.back();
+        for (int a = 0; a < 3; a++) { pr.p[a][1] = O.f[a]; pr.n[a][1] = O.f[3 + a]; }
+        pr.index[1] = O.index;
+      }
+      n_planes++;
+    } else if (O.type == CTR_OBJ_MESH) { if (O.tri_count) meshes_in.push_back(O); }  // an empty mesh is never hit
     else oloop.push_back(O);
   }
   // top-level BVH over the mesh boxes, one mesh per leaf (same node layout as the per-mesh trees)
@@ -459,11 +473,11 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->tlas_root = tlas_root;
   s->tlas_begin = tlas_begin;
   for (int q = 0; q < 3; q++) { s->tl_mn[q] = tl_mn[q]; s->tl_mx[q] = tl_mx[q]; }
-  s->n_planes = (uint32_t)planes.size();
+  s->n_planes = n_planes;
   if ((er = upload((void **)&s->d_objs, objs.data(), objs.size() * sizeof(DObj))) != hipSuccess ||
       (er = upload((void **)&s->d_oloop, oloop.data(), oloop.size() * sizeof(DObj))) != hipSuccess ||
       (er = upload((void **)&s->d_meshes, meshes.data(), meshes.size() * sizeof(DObj))) != hipSuccess ||
-      (er = upload((void **)&s->d_planes, planes.data(), planes.size() * sizeof(DPlane))) != hipSuccess ||
+      (er = upload((void **)&s->d_planes, planes.data(), planes.size() * sizeof(DPlanePair))) != hipSuccess ||
       (er = upload((void **)&s->d_tris, tris.data(), tris.size() * sizeof(DTri))) != hipSuccess ||
       (er = upload((void **)&s->d_nodes, nodes.data(), nodes.size() * sizeof(DNode))) != hipSuccess ||
       (er = upload((void **)&s->d_gnorm, gn.data(), gn.size() * sizeof(float))) != hipSuccess ||

@@ -145,7 +145,7 @@ struct KArgs {
   const CADDR DObj *meshes;    // meshes with >= 1 triangle, in top-level-BVH leaf order
   uint32_t n_mesh, tlas_root, tlas_begin;
   float tl_mn[3], tl_mx[3];    // box of all meshes (margin of the top-level walk)
-  const CADDR DPlane *planes;
+  const CADDR DPlanePair *planes;
   uint32_t n_oloop, n_planes;
   const CADDR DTri *tris;
   const CADDR DNode *nodes;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     {
       mask_t live_m = BALLOT(live);
       // one plane against the live lanes; returns false when every lane has retired (any-hit)
-      auto plane_test = [&](const auto &P, float num, float den) -> bool {
+      auto plane_test = [&](uint32_t pidx, float num, float den) -> bool {
         // The IEEE division is only worth doing where the quotient can matter: skip it (for the
         // whole wave) when a 1-ulp reciprocal already proves t0 < min_t or t0 >= the current bound.
         const float ta = num * __builtin_amdgcn_rcpf(den);
@@ -338,7 +338,6 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           // isfinite && min_t <= t0 (plane) && t0 > min_t (ray_cast.hpp:43)  ==  finite && t0 > min_t
           if (__builtin_isfinite(t0) && t0 > min_t) {
             // ray_cast.hpp:43: strict <, first object in scene order wins ties
-            const uint32_t pidx = P.index;
             if (t0 < best || (t0 == best && (int)pidx < bobj)) { best = t0; bobj = (int)pidx; btri = -1; }
             if (anyhit_cast && t0 < light_dist) retire = true;
           }
@@ -349,18 +348,21 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         }
         return true;
       };
-      // two planes per trip of the loop: the second record is requested while the first is being
-      // worked on (scalar-load round trips, not arithmetic, are most of a wave's life)
+      // Two planes per trip of the loop, from one 64-byte record with interleaved coordinates: the
+      // numerators (point - origin).normal and denominators dir.normal of BOTH planes come from packed
+      // f32 multiplies and adds — the reference's operations in the reference's order
+      // (vector.hpp dot: x*x' + y*y' + z*z' left to right), two at a time.
+      const float2_ rox = {ro.x, ro.x}, roy = {ro.y, ro.y}, roz = {ro.z, ro.z};
+      const float2_ rdx = {rd.x, rd.x}, rdy = {rd.y, rd.y}, rdz = {rd.z, rd.z};
       for (uint32_t p = 0; p < A.n_planes; p += 2) {
-        const bool two = p + 1 < A.n_planes;
-        const CADDR DPlane &P0 = A.planes[p];
-        const CADDR DPlane &P1 = A.planes[two ? p + 1 : p];
-        const V3 n0 = mk(P0.nx, P0.ny, P0.nz), n1 = mk(P1.nx, P1.ny, P1.nz);
-        const float num0 = vdot(vsub(mk(P0.px, P0.py, P0.pz), ro), n0), den0 = vdot(rd, n0);
-        const float num1 = vdot(vsub(mk(P1.px, P1.py, P1.pz), ro), n1), den1 = vdot(rd, n1);
-        if (!plane_test(P0, num0, den0)) break;
-        if (two) {
-          if (!plane_test(P1, num1, den1)) break;
+        const CADDR DPlanePair &P = A.planes[p >> 1];
+        const float2_ nx = ldpair(P.n[0]), ny = ldpair(P.n[1]), nz = ldpair(P.n[2]);
+        const float2_ dx = ldpair(P.p[0]) - rox, dy = ldpair(P.p[1]) - roy, dz = ldpair(P.p[2]) - roz;
+        const float2_ num = (dx * nx + dy * ny) + dz * nz;
+        const float2_ den = (rdx * nx + rdy * ny) + rdz * nz;
+        if (!plane_test(P.index[0], num.x, den.x)) break;
+        if (P.index[1] != CTR_PLANE_PAD) {
+          if (!plane_test(P.index[1], num.y, den.y)) break;
         }
       }
       if (ANYHIT) live = INVB(live_m);
@@ -1223,7 +1225,7 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.tlas_root = L.tlas_root;
   A.tlas_begin = L.tlas_begin;
   for (int q = 0; q < 3; q++) { A.tl_mn[q] = L.tl_mn[q]; A.tl_mx[q] = L.tl_mx[q]; }
-  A.planes = (const CADDR DPlane *)L.planes;
+  A.planes = (const CADDR DPlanePair *)L.planes;
   A.n_oloop = L.n_oloop;
   A.n_planes = L.n_planes;
   A.tris = (const CADDR DTri *)L.tris;

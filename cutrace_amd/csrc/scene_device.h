@@ -55,15 +55,20 @@ struct DObj {
 };
 static_assert(sizeof(DObj) == 64, "DObj must be 64 bytes");
 
-// planes get their own dense array and loop (one 32-byte s_load_dwordx8 each, no type dispatch):
-// box scenes are mostly planes, and every cast visits every one of them
-struct DPlane {
-  float px, py, pz;     // point
-  float nx, ny, nz;     // normal
-  uint32_t index;       // position in the scene's object list
-  uint32_t mat;
+// planes get their own dense array and loop (no type dispatch): box scenes are mostly planes, and every
+// cast visits every one of them.  Two planes share one 64-byte record with their coordinates
+// interleaved, so that (plane 0, plane 1) of one coordinate is an aligned SGPR pair and the two
+// numerators / denominators are evaluated with packed f32 instructions — same multiplies and adds in
+// the same order as the scalar form, two at a time.  An odd plane count pads the last record with a
+// copy of its first plane (index[1] = CTR_PLANE_PAD: never tested).
+struct DPlanePair {
+  float p[3][2];        // point:  p[axis][which plane]
+  float n[3][2];        // normal
+  uint32_t index[2];    // position in the scene's object list
+  uint32_t pad[2];
 };
-static_assert(sizeof(DPlane) == 32, "DPlane must be 32 bytes");
+static_assert(sizeof(DPlanePair) == 64, "DPlanePair must be 64 bytes");
+#define CTR_PLANE_PAD 0xFFFFFFFFu
 
 struct DLight {
   uint32_t type;        // CTR_LIGHT_*
@@ -113,7 +118,7 @@ struct RenderLaunch {
   const DObj *meshes;      // non-empty meshes in top-level-BVH leaf order
   uint32_t n_mesh, tlas_root, tlas_begin;
   float tl_mn[3], tl_mx[3];
-  const DPlane *planes;
+  const DPlanePair *planes;  // ceil(n_planes / 2) records
   uint32_t n_oloop, n_planes;
   const DTri *tris;
   const void *nodes;    // DNode[] (bvh.h)
