@@ -586,7 +586,10 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               const float sA2 = __uint_as_float(__float_as_uint(A2) ^ sgn);
               const float absa = fabsf(alpha);
               const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-              const float E = fmaxf(dmax * T.ke, T.ke2) * cmax;  // kappa * max(dmax,emax) * emax * cmax
+              // kappa * max(dmax,emax) * emax * cmax; both operands are >= 0, so the maximum is taken on the
+              // bit patterns (fmaxf would first canonicalise the loaded ke2: one more VALU op per triangle)
+              const uint32_t e_a = __float_as_uint(dmax * T.ke), e_b = __float_as_uint(T.ke2);
+              const float E = __uint_as_float(e_a > e_b ? e_a : e_b) * cmax;
               const mask_t rej = FCMP(sA1, -E, FC_OLT) | FCMP(sA2, -E, FC_OLT) | FCMP(sA1 + sA2, absa + E, FC_OGT);
               const mask_t flat_m = FCMP(absa, E, FC_OLE);  // alpha within rounding of 0: always a candidate
               c_m = lanes_m & (~rej | flat_m);
