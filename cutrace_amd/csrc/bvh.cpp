@@ -124,15 +124,23 @@ struct Builder {
 
 }  // namespace
 
+static void bvh_build_mode(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vector<DNode> &nodes,
+                           std::vector<uint32_t> &order, uint32_t &root, bool force_median);
+
 void bvh_build(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vector<DNode> &nodes,
                std::vector<uint32_t> &order, uint32_t &root) {
+  bvh_build_mode(prims, leaf_size, nodes, order, root, false);
+}
+
+static void bvh_build_mode(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vector<DNode> &nodes,
+                           std::vector<uint32_t> &order, uint32_t &root, bool force_median) {
   nodes.clear();
   order.resize(prims.size());
   root = BVH_LEAF_FLAG;  // empty leaf
   if (prims.empty()) return;
   if (leaf_size < 1) leaf_size = 1;
   if (leaf_size > BVH_MAX_LEAF) leaf_size = BVH_MAX_LEAF;
-  for (int attempt = 0; attempt < 2; attempt++) {
+  for (int attempt = force_median ? 1 : 0; attempt < 2; attempt++) {
     nodes.clear();
     for (uint32_t i = 0; i < prims.size(); i++) order[i] = i;
     Builder b{prims, leaf_size, attempt == 1, nodes, order};
@@ -148,4 +156,120 @@ void bvh_build(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vect
   };
   sort_leaf(root);
   for (const DNode &n : nodes) { sort_leaf(n.left); sort_leaf(n.right); }
+}
+
+
+// ---- collapse to four-wide nodes ----
+namespace {
+
+struct Child4 {
+  uint32_t desc;        // binary-tree descriptor (leaf, or inner index into the binary node array)
+  float mn[3], mx[3];
+  float area() const {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Collapser {
+  const std::vector<DNode> &n2;
+  std::vector<DNode4> &n4;
+  bool balanced;  // expand both seeds once (depth halves exactly) instead of largest-area-first
+  int max_depth = 0;
+
+  static Child4 child_of(const DNode &n, int c) {
+    Child4 k;
+    k.desc = c ? n.right : n.left;
+    for (int a = 0; a < 3; a++) { k.mn[a] = n.mn[a][c]; k.mx[a] = n.mx[a][c]; }
+    return k;
+  }
+
+  // emits the four-wide node for the binary subtree whose two top children are `seed`; returns its index
+  uint32_t emit(std::vector<Child4> kids, int depth) {
+    max_depth = std::max(max_depth, depth);
+    if (balanced) {
+      const size_t n0 = kids.size();
+      for (size_t i = 0; i < n0; i++)
+        if (!(kids[i].desc & BVH_LEAF_FLAG)) {
+          const DNode &n = n2[kids[i].desc];
+          kids[i] = child_of(n, 0);
+          kids.push_back(child_of(n, 1));
+        }
+    }
+    while (!balanced && kids.size() < 4) {
+      int best = -1;
+      float best_area = -1.f;
+      for (size_t i = 0; i < kids.size(); i++)
+        if (!(kids[i].desc & BVH_LEAF_FLAG) && kids[i].area() > best_area) { best_area = kids[i].area(); best = (int)i; }
+      if (best < 0) break;
+      const DNode &n = n2[kids[best].desc];
+      kids[best] = child_of(n, 0);
+      kids.push_back(child_of(n, 1));
+    }
+    // order axis: largest spread of the children's centroids
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const Child4 &k : kids)
+      for (int a = 0; a < 3; a++) {
+        const float c = 0.5f * (k.mn[a] + k.mx[a]);
+        cmin[a] = std::min(cmin[a], c);
+        cmax[a] = std::max(cmax[a], c);
+      }
+    int axis = 0;
+    for (int a = 1; a < 3; a++)
+      if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+    std::stable_sort(kids.begin(), kids.end(), [&](const Child4 &x, const Child4 &y) {
+      return x.mn[axis] + x.mx[axis] < y.mn[axis] + y.mx[axis];
+    });
+    const uint32_t me = (uint32_t)n4.size();
+    n4.emplace_back();
+    DNode4 nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.axis = (uint32_t)axis;
+    for (int c = 0; c < 4; c++) {
+      if (c < (int)kids.size()) {
+        for (int a = 0; a < 3; a++) { nd.lo[a][c] = kids[c].mn[a]; nd.hi[a][c] = kids[c].mx[a]; }
+        if (kids[c].desc & BVH_LEAF_FLAG) {
+          nd.child[c] = kids[c].desc;
+        } else {
+          const DNode &n = n2[kids[c].desc];
+          nd.child[c] = emit({child_of(n, 0), child_of(n, 1)}, depth + 1);
+        }
+      } else {
+        // unused slot: a point far away (never inside a finite ray interval) and an empty leaf
+        for (int a = 0; a < 3; a++) { nd.lo[a][c] = std::numeric_limits<float>::max(); nd.hi[a][c] = std::numeric_limits<float>::max(); }
+        nd.child[c] = BVH_LEAF_FLAG;
+      }
+    }
+    n4[me] = nd;
+    return me;
+  }
+};
+
+}  // namespace
+
+void bvh4_build(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vector<DNode4> &nodes4,
+                std::vector<uint32_t> &order) {
+  nodes4.clear();
+  order.clear();
+  if (prims.empty()) return;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    std::vector<DNode> n2;
+    uint32_t root = BVH_LEAF_FLAG;
+    bvh_build_mode(prims, leaf_size, n2, order, root, attempt == 1);
+    nodes4.clear();
+    Collapser c{n2, nodes4, attempt == 1};
+    if (root & BVH_LEAF_FLAG) {
+      // the whole mesh fits one leaf: a root with that single child (keeps the walk free of special cases)
+      Child4 k;
+      k.desc = root;
+      for (int a = 0; a < 3; a++) { k.mn[a] = INFINITY; k.mx[a] = -INFINITY; }
+      for (const BvhInput &p : prims)
+        for (int a = 0; a < 3; a++) { k.mn[a] = std::min(k.mn[a], p.mn[a]); k.mx[a] = std::max(k.mx[a], p.mx[a]); }
+      c.emit({k}, 0);
+    } else {
+      const DNode &n = n2[root];
+      c.emit({Collapser::child_of(n, 0), Collapser::child_of(n, 1)}, 0);
+    }
+    if (c.max_depth <= BVH4_MAX_DEPTH) break;  // else: balanced binary tree, depth log2(n) -> four-wide depth ~ half
+  }
 }

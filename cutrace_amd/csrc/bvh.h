@@ -36,6 +36,23 @@ struct DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
+// Four-wide node for the per-mesh walk (the top-level tree over meshes keeps DNode): 128 bytes = two
+// s_load_dwordx16.  One visit tests FOUR child boxes (pairs of children per v_pk_fma_f32), so the chain of
+// dependent scalar loads a cast walks through is about half as long as with two-wide nodes, and the
+// per-visit bookkeeping (address, stack, branches) is paid half as often.  Built by collapsing the
+// binned-SAH binary tree (largest-area child expanded first).  Children are sorted by centroid along
+// `axis`; a ray that points the other way visits them in reverse.  Unused slots hold a far-away point box
+// and an empty leaf.
+struct DNode4 {
+  float lo[3][4];        // min corners: lo[a][child]; (0,1) and (2,3) are aligned SGPR pairs
+  float hi[3][4];        // max corners
+  uint32_t child[4];     // child descriptors (see above), empty slot = BVH_LEAF_FLAG (leaf of 0 triangles)
+  uint32_t axis;         // order axis
+  uint32_t pad[3];
+};
+static_assert(sizeof(DNode4) == 128, "DNode4 must be two 64-byte lines");
+#define BVH4_MAX_DEPTH 20  // the walk pushes at most 3 entries per level onto a 64-entry stack
+
 struct BvhInput {
   // per triangle: bounds and centroid
   float mn[3], mx[3], c[3];
@@ -46,5 +63,11 @@ struct BvhInput {
 // permutation such that permuted[i] = original[order[i]].
 void bvh_build(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vector<DNode> &nodes,
                std::vector<uint32_t> &order, uint32_t &root);
+
+// The same tree collapsed to four-wide nodes.  `nodes4` always holds at least one node when there is at
+// least one primitive (a mesh that fits one leaf gets a root with one child), node 0 is the root;
+// depth <= BVH4_MAX_DEPTH is guaranteed (balanced rebuild otherwise).
+void bvh4_build(const std::vector<BvhInput> &prims, uint32_t leaf_size, std::vector<DNode4> &nodes4,
+                std::vector<uint32_t> &order);
 
 #endif

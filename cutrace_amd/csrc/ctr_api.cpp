@@ -104,6 +104,7 @@ struct ctr_scene {
   uint32_t n_oloop = 0, n_planes = 0;
   DTri *d_tris = nullptr;
   DNode *d_nodes = nullptr;
+  DNode4 *d_nodes4 = nullptr;
   float *d_gnorm = nullptr;
   DLight *d_lights = nullptr;
   DMat *d_mats = nullptr;
@@ -140,9 +141,6 @@ struct ctr_scene {
     if (all_opaque && !(user_variant & CTR_VAR_NO_ANYHIT) && !count) kv |= KV_ANYHIT;
     if (!(user_variant & CTR_VAR_NO_CLUSTER) && !count) kv |= KV_BVH;
     if (!(user_variant & CTR_VAR_EXACT_POW)) kv |= KV_FASTPOW;
-    // The vector-memory variant exists for comparison only: the scalar path measured faster at every
-    // mesh size tried (1k..64k triangles: 2.37 vs 2.56 ms, 5.66 vs 6.11 ms), so it is never auto-selected.
-    if ((user_variant & CTR_VAR_VMEM) && !(user_variant & CTR_VAR_SMEM)) kv |= KV_VMEM;
     if (count) kv = KV_PREFILTER | KV_COUNT;  // the counting launch walks like the reference
     if (user_variant & CTR_VAR_STATS) kv = KV_STATS | (all_opaque ? KV_ANYHIT : 0u);
     return kv;
@@ -202,6 +200,7 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.n_planes = s->n_planes;
   L.tris = s->d_tris;
   L.nodes = s->d_nodes;
+  L.nodes4 = s->d_nodes4;
   L.gnorm = s->d_gnorm;
   L.lights = s->d_lights;
   L.mats = s->d_mats;
@@ -324,7 +323,8 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   //      tie-breaks), stand-alone triangles appended ----
   std::vector<DObj> objs(d->n_objects);
   std::vector<DTri> tris;
-  std::vector<DNode> nodes;
+  std::vector<DNode> nodes;    // top-level tree
+  std::vector<DNode4> nodes4;  // per-mesh trees
   std::vector<float> gn;
   tris.reserve(d->n_triangles + d->n_objects);
   bool has_mesh = false;
@@ -360,16 +360,15 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
           }
         }
         if (n > 0xFFFFFFu) return fail(CTR_E_INVALID, "object #" + std::to_string(i) + ": mesh has more than 2^24 triangles");
-        std::vector<DNode> mnodes;
+        std::vector<DNode4> mnodes;
         std::vector<uint32_t> order;
-        uint32_t root = 0;
-        bvh_build(prims, BVH_LEAF, mnodes, order, root);
+        bvh4_build(prims, BVH_LEAF, mnodes, order);
         O.tri_begin = (uint32_t)tris.size();
         O.tri_count = n;
-        O.node_begin = (uint32_t)nodes.size();
+        O.node_begin = (uint32_t)nodes4.size();
         O.node_count = (uint32_t)mnodes.size();
-        O.bvh_root = root;  // child descriptors stay relative to the mesh's first node / first triangle
-        nodes.insert(nodes.end(), mnodes.begin(), mnodes.end());
+        O.bvh_root = 0;  // node 0 of the mesh; child descriptors stay relative to the mesh's first node / first triangle
+        nodes4.insert(nodes4.end(), mnodes.begin(), mnodes.end());
         tris.resize(tris.size() + n);
         gn.resize(4 * tris.size());
         for (uint32_t k = 0; k < n; k++) {
@@ -454,7 +453,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->n_light = (uint32_t)lights.size();
   s->n_mat = (uint32_t)mats.size();
   s->has_mesh = has_mesh;
-  s->mesh_bytes = tris.size() * sizeof(DTri) + nodes.size() * sizeof(DNode);
+  s->mesh_bytes = tris.size() * sizeof(DTri) + nodes.size() * sizeof(DNode) + nodes4.size() * sizeof(DNode4);
   s->all_opaque = all_opaque;
   s->need_cold = need_cold;
   DCam cam = to_dcam(d->cam);
@@ -480,6 +479,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
       (er = upload((void **)&s->d_planes, planes.data(), planes.size() * sizeof(DPlanePair))) != hipSuccess ||
       (er = upload((void **)&s->d_tris, tris.data(), tris.size() * sizeof(DTri))) != hipSuccess ||
       (er = upload((void **)&s->d_nodes, nodes.data(), nodes.size() * sizeof(DNode))) != hipSuccess ||
+      (er = upload((void **)&s->d_nodes4, nodes4.data(), nodes4.size() * sizeof(DNode4))) != hipSuccess ||
       (er = upload((void **)&s->d_gnorm, gn.data(), gn.size() * sizeof(float))) != hipSuccess ||
       (er = upload((void **)&s->d_lights, lights.data(), lights.size() * sizeof(DLight))) != hipSuccess ||
       (er = upload((void **)&s->d_mats, mats.data(), mats.size() * sizeof(DMat))) != hipSuccess ||
@@ -523,7 +523,7 @@ int ctr_scene_set_cameras(ctr_scene *s, const ctr_camera *cams, uint32_t n) {
 void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
+  for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_nodes4, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
                   (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -651,9 +651,12 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
     fprintf(stderr, "cutrace_amd stats: wave_casts=%llu nodes=%llu tri_prefilter=%llu tri_exact=%llu mesh_entries=%llu "
                     "active_lanes=%llu kernel_ms=%.3f\n", cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], cnt[9], ms);
   if (aabb_tris) *aabb_tris = cnt[2];
-  if (cnt[13])  // CTR_TIMING diagnostic build
-    fprintf(stderr, "cutrace_amd timing (wave-cycles): object_loop=%llu mesh=%llu continuation=%llu wave_total=%llu "
-                    "kernel_ms=%.3f\n", cnt[10], cnt[11], cnt[12], cnt[13], ms);
+  if (cnt[13] && !(s->user_variant & CTR_VAR_STATS))  // CTR_TIMING diagnostic build: share of the waves' lifetime
+    fprintf(stderr, "cutrace_amd timing (%% of wave cycles): cast_setup=%.1f planes=%.1f object_loop=%.1f tlas+aabb=%.1f "
+                    "mesh_setup=%.1f bvh_nodes=%.1f leaves=%.1f cont_mode=%.1f cont_rest=%.1f | wave_total=%llu kernel_ms=%.3f\n",
+            100.0 * cnt[4] / cnt[13], 100.0 * cnt[5] / cnt[13], 100.0 * cnt[6] / cnt[13], 100.0 * cnt[7] / cnt[13],
+            100.0 * cnt[8] / cnt[13], 100.0 * cnt[9] / cnt[13], 100.0 * cnt[10] / cnt[13], 100.0 * cnt[11] / cnt[13],
+            100.0 * cnt[12] / cnt[13], cnt[13], ms);
   auto t1 = std::chrono::high_resolution_clock::now();
   if (stats) {
     stats->kernel_ms = ms;

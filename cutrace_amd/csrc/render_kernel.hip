@@ -45,6 +45,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "cutrace_amd.h"
 #include "scene_device.h"
@@ -58,6 +59,10 @@
 #define FCMP(a, b, pred) __builtin_amdgcn_fcmpf((a), (b), (pred))  /* v_cmp straight into a lane mask */
 enum { FC_OGT = 2, FC_OGE = 3, FC_OLT = 4, FC_OLE = 5 };          /* LLVM FCmp predicate numbers */
 #define TL_NONE 0x7FFFFFFFu                                        /* "no more top-level items" */
+
+// v_writelane_b32 with a wave-uniform value and lane select: this clang has no __builtin for it, so the
+// LLVM intrinsic is bound by name (the compiler then routes the lane select through M0 by itself)
+extern "C" __device__ uint32_t ctr_writelane(uint32_t value, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
 
 namespace {
 
@@ -105,8 +110,28 @@ __device__ __forceinline__ float slab_hi(float ax, float bx, float ay, float by,
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
   return r;
 }
+// the same with one more bound folded in: max(entry distances, mn) / min(exit distances, mx)
+__device__ __forceinline__ float slab_lo4(float ax, float bx, float ay, float by, float az, float bz, float mn) {
+  float x, y, z, r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(x) : "v"(ax), "v"(bx));
+  asm("v_min_f32 %0, %1, %2" : "=v"(y) : "v"(ay), "v"(by));
+  asm("v_min_f32 %0, %1, %2" : "=v"(z) : "v"(az), "v"(bz));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(mn));
+  return r;
+}
+__device__ __forceinline__ float slab_hi4(float ax, float bx, float ay, float by, float az, float bz, float mx) {
+  float x, y, z, r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(ax), "v"(bx));
+  asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(ay), "v"(by));
+  asm("v_max_f32 %0, %1, %2" : "=v"(z) : "v"(az), "v"(bz));
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(mx));
+  return r;
+}
 // two adjacent floats of a wave-uniform record as one aligned SGPR pair
 __device__ __forceinline__ float2_ ldpair(const CADDR float (&p)[2]) { return *(const CADDR float2_ *)p; }
+__device__ __forceinline__ float2_ ldpair2(const CADDR float *p) { return *(const CADDR float2_ *)p; }
 
 // ---- inc/vector.hpp, same operation order -------------------------------------
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -148,9 +173,8 @@ struct KArgs {
   const CADDR DPlanePair *planes;
   uint32_t n_oloop, n_planes;
   const CADDR DTri *tris;
-  const CADDR DNode *nodes;
-  const DTri *tris_g;          // the same arrays through the global address space (VMEM variant)
-  const DNode *nodes_g;
+  const CADDR DNode *nodes;    // top-level tree over the meshes (two-wide nodes)
+  const CADDR DNode4 *nodes4;  // per-mesh trees (four-wide nodes)
   const CADDR float *gnorm;
   const CADDR DLight *lights;
   const CADDR DMat *mats;
@@ -187,18 +211,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   constexpr bool STATS = (KV & KV_STATS) != 0;
 #endif
   constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
-  // VMEM: BVH nodes and triangles travel through the vector memory path (same address in every
-  // lane, values in VGPRs) instead of the scalar cache.  The scalar cache sustains very few
-  // outstanding misses: past a few hundred KB of mesh data its miss queue, not arithmetic, sets
-  // the frame time (64k-triangle bunny: 76 ms scalar vs the vector path).
-  constexpr bool VMEM = (KV & KV_VMEM) != 0;
   // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast
   unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
 #ifdef CTR_TIMING
-  // diagnostic build only: shader-clock stamps per wave -> shards[10..13] = {object loop, mesh branch,
-  // continuation, whole wave}
-  unsigned long long tm[4] = {0, 0, 0, 0};
+  // diagnostic build only: shader-clock stamps per wave -> shards[4..13] = {cast setup, planes, object
+  // loop, top-level walk + mesh AABB, mesh entry setup, BVH walk without leaves, leaves, radiance
+  // continuation, rest of the continuation, whole wave}
+  unsigned long long tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long tm_start = __builtin_readcyclecounter();
 #define TSTAMP(v) const unsigned long long v = __builtin_readcyclecounter()
 #define TACC(i, a, b) tm[i] += (b) - (a)
@@ -291,6 +311,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   unsigned long long n_aabb_tris = 0;
 
   while (BALLOT(mode != M_DONE) != 0ull) {
+    TSTAMP(t_trip0);
     const bool active = mode != M_DONE;
     const bool shadow_cast = mode == M_SHADOW;
     n_casts += (unsigned long long)__builtin_popcountll(BALLOT(active));
@@ -318,27 +339,38 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     }
 
     TSTAMP(t_loop0);
+    TACC(0, t_trip0, t_loop0);
     typedef unsigned long long mask_t;
     const bool anyhit_cast = ANYHIT && shadow_cast;
     // ---- planes: plane::intersect, default_schema.hpp:189-201, all in lane masks ----
     {
       mask_t live_m = BALLOT(live);
-      // one plane against the live lanes; returns false when every lane has retired (any-hit)
-      auto plane_test = [&](uint32_t pidx, float num, float den) -> bool {
-        // The IEEE division is only worth doing where the quotient can matter: skip it (for the
-        // whole wave) when a 1-ulp reciprocal already proves t0 < min_t or t0 >= the current bound.
-        const float ta = num * __builtin_amdgcn_rcpf(den);
-        const float mrg = fabsf(ta) * 0x1p-18f + 1e-30f;
-        const float lim_hi = anyhit_cast ? light_dist : best;
-        const mask_t need_m = live_m & ~(FCMP(ta + mrg, min_t, FC_OLT) | FCMP(ta - mrg, lim_hi, FC_OGT));  // NaN/inf -> needed
-        if (need_m == 0ull) return true;
+      // t0 = num/den is an IEEE division, and it is only worth doing where the quotient can matter.
+      // Classification WITHOUT dividing (and without a reciprocal): with num' = num * sign(den) and
+      // den' = |den| the quotient is num'/den', so
+      //   t0 <= min_t for certain  if  num' < (min_t - 2^-21|min_t|) * den' - tiny
+      //   t0 >  lim   for certain  if  num' > (lim   + 2^-21|lim|)   * den' + tiny
+      // (2^-21 covers the roundings of the two products and of the division itself; tiny = 1e-37 covers
+      // products that underflow; a NaN compares false = "needed"; den = 0 gives num' <> -+tiny, and the
+      // quotient is then infinite or NaN, which plane::intersect rejects as not finite.)
+      // lim = the light for a deciding shadow ray, else the nearest hit so far.
+      const float mt_lo = min_t - fabsf(min_t) * 0x1p-21f;
+      float lhv = anyhit_cast ? light_dist : best;
+      lhv = lhv + fabsf(lhv) * 0x1p-21f;
+      float tiny = 1e-37f;
+      asm volatile("" : "+v"(tiny));  // keep it in a VGPR: a literal operand would halve the FMA's issue rate
+      // one plane against the lanes in need_m; returns false when every lane has retired (any-hit)
+      auto plane_exact = [&](uint32_t pidx, float num, float den, mask_t need_m) -> bool {
         bool retire = false;
         if (INVB(need_m)) {
           const float t0 = num / den;
           // isfinite && min_t <= t0 (plane) && t0 > min_t (ray_cast.hpp:43)  ==  finite && t0 > min_t
           if (__builtin_isfinite(t0) && t0 > min_t) {
             // ray_cast.hpp:43: strict <, first object in scene order wins ties
-            if (t0 < best || (t0 == best && (int)pidx < bobj)) { best = t0; bobj = (int)pidx; btri = -1; }
+            if (t0 < best || (t0 == best && (int)pidx < bobj)) {
+              best = t0; bobj = (int)pidx; btri = -1;
+              if (!anyhit_cast) lhv = t0 + fabsf(t0) * 0x1p-21f;
+            }
             if (anyhit_cast && t0 < light_dist) retire = true;
           }
         }
@@ -348,25 +380,58 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         }
         return true;
       };
-      // Two planes per trip of the loop, from one 64-byte record with interleaved coordinates: the
-      // numerators (point - origin).normal and denominators dir.normal of BOTH planes come from packed
-      // f32 multiplies and adds — the reference's operations in the reference's order
-      // (vector.hpp dot: x*x' + y*y' + z*z' left to right), two at a time.
+      auto plane_test = [&](uint32_t pidx, float num, float den) -> bool {
+        const float nump = __uint_as_float(__float_as_uint(num) ^ (__float_as_uint(den) & 0x80000000u));
+        const float denp = fabsf(den);
+        const mask_t need_m = live_m & ~(FCMP(nump, __builtin_fmaf(mt_lo, denp, -tiny), FC_OLT) |
+                                         FCMP(nump, __builtin_fmaf(lhv, denp, tiny), FC_OGT));
+        if (need_m == 0ull) return true;
+        return plane_exact(pidx, num, den, need_m);
+      };
+      // Two planes per 64-byte record with interleaved coordinates: the numerators (point - origin).normal
+      // and denominators dir.normal of BOTH planes come from packed f32 multiplies and adds — the
+      // reference's operations in the reference's order (vector.hpp dot: x*x' + y*y' + z*z' left to
+      // right), two at a time.  Three records (six planes) are fetched and evaluated per trip, so a box
+      // room costs ONE scalar-load round trip per cast instead of three dependent ones.
       const float2_ rox = {ro.x, ro.x}, roy = {ro.y, ro.y}, roz = {ro.z, ro.z};
       const float2_ rdx = {rd.x, rd.x}, rdy = {rd.y, rd.y}, rdz = {rd.z, rd.z};
-      for (uint32_t p = 0; p < A.n_planes; p += 2) {
-        const CADDR DPlanePair &P = A.planes[p >> 1];
+      auto num_den = [&](const CADDR DPlanePair &P, float2_ &num, float2_ &den) {
         const float2_ nx = ldpair(P.n[0]), ny = ldpair(P.n[1]), nz = ldpair(P.n[2]);
         const float2_ dx = ldpair(P.p[0]) - rox, dy = ldpair(P.p[1]) - roy, dz = ldpair(P.p[2]) - roz;
-        const float2_ num = (dx * nx + dy * ny) + dz * nz;
-        const float2_ den = (rdx * nx + rdy * ny) + rdz * nz;
-        if (!plane_test(P.index[0], num.x, den.x)) break;
-        if (P.index[1] != CTR_PLANE_PAD) {
-          if (!plane_test(P.index[1], num.y, den.y)) break;
+        num = (dx * nx + dy * ny) + dz * nz;
+        den = (rdx * nx + rdy * ny) + rdz * nz;
+      };
+      const uint32_t n_pairs = (A.n_planes + 1u) >> 1;
+      for (uint32_t p = 0; p < n_pairs; p += 3) {
+        const uint32_t p1 = p + 1 < n_pairs ? p + 1 : p, p2 = p + 2 < n_pairs ? p + 2 : p;
+        const CADDR DPlanePair &P0 = A.planes[p], &P1 = A.planes[p1], &P2 = A.planes[p2];
+        float2_ num0, den0, num1, den1, num2, den2;
+        num_den(P0, num0, den0);
+        num_den(P1, num1, den1);
+        num_den(P2, num2, den2);
+        const uint32_t i00 = P0.index[0], i01 = P0.index[1], i10 = P1.index[0], i11 = P1.index[1], i20 = P2.index[0],
+                       i21 = P2.index[1];
+        if (!plane_test(i00, num0.x, den0.x)) break;
+        if (i01 != CTR_PLANE_PAD) {
+          if (!plane_test(i01, num0.y, den0.y)) break;
+        }
+        if (p1 != p) {
+          if (!plane_test(i10, num1.x, den1.x)) break;
+          if (i11 != CTR_PLANE_PAD) {
+            if (!plane_test(i11, num1.y, den1.y)) break;
+          }
+        }
+        if (p2 != p) {
+          if (!plane_test(i20, num2.x, den2.x)) break;
+          if (i21 != CTR_PLANE_PAD) {
+            if (!plane_test(i21, num2.y, den2.y)) break;
+          }
         }
       }
       if (ANYHIT) live = INVB(live_m);
     }
+    TSTAMP(t_planes1);
+    TACC(1, t_loop0, t_planes1);
     // ---- spheres and stand-alone triangles, scene order ----
     // sphere::intersect normalises the direction first (default_schema.hpp:227): once per cast (at the
     // first sphere the cast meets), not once per sphere
@@ -434,10 +499,13 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     // ---- meshes, reached through a top-level BVH over their boxes (bvh.h layout, one mesh per leaf)
     //      so that a cast only looks at meshes some lane's ray can touch.  Visiting order does not
     //      matter: the winner is the lexicographic minimum of (t, scene index). ----
+    TSTAMP(t_oloop1);
+    TACC(2, t_planes1, t_oloop1);
     if (A.n_mesh != 0u) {
       uint32_t t_pend = A.tlas_root;           // next top-level item: inner node or mesh leaf
       uint32_t t_stack_v = 0, t_sp = 0;        // wave-uniform stack in the lanes of one VGPR
       for (;;) {
+        TSTAMP(t_tl0);
         if (ANYHIT) {
           if (BALLOT(live) == 0ull) break;
         }
@@ -466,10 +534,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             const bool hl = t_hits(0) != 0ull, hr = t_hits(1) != 0ull;
             const uint32_t dl = N.left, dr = N.right;
             if (hl && hr) {
-              asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
-                           : "+v"(t_stack_v)
-                           : "s"(__builtin_amdgcn_readfirstlane(dr)), "s"(__builtin_amdgcn_readfirstlane(t_sp))
-                           : "m0");
+              t_stack_v = ctr_writelane(__builtin_amdgcn_readfirstlane(dr),
+                                                       __builtin_amdgcn_readfirstlane(t_sp), t_stack_v);
               t_sp++;
               t_pend = dl;
             } else if (hl) {
@@ -500,7 +566,6 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         {
           // Everything in this branch works on 64-bit lane masks (v_cmp results kept in SGPRs and
           // combined on the scalar unit) instead of per-lane booleans.
-          TSTAMP(t_mesh0);
           const mask_t live_m = BALLOT(live);
           // ---- mesh::bound_intersects, default_schema.hpp:99-114 ----
           // The reference's slab test needs three IEEE divisions (1/dir) per ray.  With 1-ulp
@@ -543,11 +608,9 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               bb_m |= border & FCMP(tmin, tmax, FC_OLE);
             }
           }
-          if (bb_m == 0ull) {  // no lane of this wave needs the mesh
-            TSTAMP(t_mesh_skip);
-            TACC(1, t_mesh0, t_mesh_skip);
-            continue;
-          }
+          TSTAMP(t_bb);
+          TACC(3, t_tl0, t_bb);
+          if (bb_m == 0ull) continue;  // no lane of this wave needs the mesh
           const mask_t bb0_m = bb_m;
           const uint32_t beg = O.tri_begin, cnt = O.tri_count;
           if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
@@ -685,12 +748,16 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             }
           };
 
+#ifdef CTR_TIMING
+          unsigned long long t_leaves = 0, t_w0 = 0;
+#endif
           if (BVH) {
-            // Walk of the mesh's BVH by the whole wave together (bvh.h): an inner node holds BOTH
-            // children's boxes, so a child no lane touches is never loaded and leaves cost no node
-            // load.  Pending inner children wait on a wave-uniform stack kept in the lanes of ONE
-            // VGPR (v_writelane / v_readlane); the child on the near side of the split axis goes
-            // first.
+            // Walk of the mesh's four-wide BVH by the whole wave together (bvh.h, DNode4): one visit =
+            // one 128-byte node = the boxes of FOUR children, tested with twelve v_pk_fma_f32 (two
+            // children per instruction).  Leaves among the hit children are tested at once, inner
+            // children wait on a wave-uniform stack kept in the lanes of ONE VGPR (v_writelane /
+            // v_readlane), nearest first: the children are stored sorted along the node's order axis
+            // and a wave whose lead ray points the other way takes them in reverse.
             // The box test is conservative: every box is widened in WORLD space by
             //   m = 2^-14 x (largest |coordinate difference| between the ray origin and the mesh box)
             // per axis ((mn - m - o)/d and (mx + m - o)/d, folded into the two FMA constants below), far
@@ -702,7 +769,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             const float mw = fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f;
             const V3 ka = mk((ro.x + mw) * ria.x, (ro.y + mw) * ria.y, (ro.z + mw) * ria.z);  // for box minima
             const V3 kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);  // for box maxima
-            const CADDR DNode *nodes = A.nodes + O.node_begin;
+            const CADDR DNode4 *nodes4 = A.nodes4 + O.node_begin;
             // direction signs of the first lane that needs the mesh decide the visiting order (speed only)
             const uint32_t lead = (uint32_t)__builtin_ctzll(bb_m);
             const uint32_t neg_bits = (__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31) |
@@ -712,107 +779,94 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             // needs with op_sel, so packing costs no extra registers
             const float2_ c_rxy = {ria.x, ria.y}, c_rzk = {ria.z, ka.x}, c_kyz = {ka.y, ka.z};
             const float2_ c_bxy = {kb.x, kb.y}, c_bz = {kb.z, 0.0f};
-            // both children's boxes at once: six v_pk_fma_f32 give the six slab distances of the left
-            // (.x) and the right (.y) box; reject only on a definite miss (NaN compares false -> entered)
-            auto box_hits2 = [&](const auto &N, mask_t &hl, mask_t &hr) {
+            // children (c, c+1) of one node: six v_pk_fma_f32 give the six slab distances of both boxes;
+            // a lane takes a child unless it misses for certain: max(entry, min_t) > min(exit, lim)
+            // (v_min/v_max drop a NaN operand, a NaN that survives compares false -> entered)
+            auto box_hits2 = [&](const CADDR DNode4 &N, int c, mask_t &ha, mask_t &hb) {
               float2_ t1x, t1y, t1z, t2x, t2y, t2z;
-              PKFMA(t1x, ldpair(N.mn[0]), c_rxy, 0, c_rzk, 1);
-              PKFMA(t1y, ldpair(N.mn[1]), c_rxy, 1, c_kyz, 0);
-              PKFMA(t1z, ldpair(N.mn[2]), c_rzk, 0, c_kyz, 1);
-              PKFMA(t2x, ldpair(N.mx[0]), c_rxy, 0, c_bxy, 0);
-              PKFMA(t2y, ldpair(N.mx[1]), c_rxy, 1, c_bxy, 1);
-              PKFMA(t2z, ldpair(N.mx[2]), c_rzk, 0, c_bz, 0);
-              // (min/max through asm as well: fminf/fmaxf on asm results would first re-canonicalise
-              //  every operand, 12 extra VALU ops per node)
-              const float lo_l = slab_lo(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x);
-              const float hi_l = slab_hi(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x);
-              const float lo_r = slab_lo(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y);
-              const float hi_r = slab_hi(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y);
-              hl = bb_m & ~(FCMP(lo_l, hi_l, FC_OGT) | FCMP(hi_l, min_t, FC_OLT) | FCMP(lo_l, lim, FC_OGT));
-              hr = bb_m & ~(FCMP(lo_r, hi_r, FC_OGT) | FCMP(hi_r, min_t, FC_OLT) | FCMP(lo_r, lim, FC_OGT));
-            };
-            // the same test with per-lane node data (vector-memory variant)
-            auto box_hits_v = [&](const DNode &Nv, int c) -> mask_t {
-              const float t1x = __builtin_fmaf(Nv.mn[0][c], ria.x, -ka.x), t2x = __builtin_fmaf(Nv.mx[0][c], ria.x, -kb.x);
-              const float t1y = __builtin_fmaf(Nv.mn[1][c], ria.y, -ka.y), t2y = __builtin_fmaf(Nv.mx[1][c], ria.y, -kb.y);
-              const float t1z = __builtin_fmaf(Nv.mn[2][c], ria.z, -ka.z), t2z = __builtin_fmaf(Nv.mx[2][c], ria.z, -kb.z);
-              const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-              const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-              return bb_m & ~(FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, lim, FC_OGT));
+              PKFMA(t1x, ldpair2(&N.lo[0][c]), c_rxy, 0, c_rzk, 1);
+              PKFMA(t1y, ldpair2(&N.lo[1][c]), c_rxy, 1, c_kyz, 0);
+              PKFMA(t1z, ldpair2(&N.lo[2][c]), c_rzk, 0, c_kyz, 1);
+              PKFMA(t2x, ldpair2(&N.hi[0][c]), c_rxy, 0, c_bxy, 0);
+              PKFMA(t2y, ldpair2(&N.hi[1][c]), c_rxy, 1, c_bxy, 1);
+              PKFMA(t2z, ldpair2(&N.hi[2][c]), c_rzk, 0, c_bz, 0);
+              const float lo_a = slab_lo4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, min_t);
+              const float hi_a = slab_hi4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, lim);
+              const float lo_b = slab_lo4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, min_t);
+              const float hi_b = slab_hi4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, lim);
+              ha = bb_m & ~FCMP(lo_a, hi_a, FC_OGT);
+              hb = bb_m & ~FCMP(lo_b, hi_b, FC_OGT);
             };
             auto leaf = [&](uint32_t desc, mask_t lanes) {
+              TSTAMP(t_leaf0);
               const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
               for (uint32_t k = 0; k < n_l; ++k) {
-                if (VMEM) {
-                  uint32_t iv = first + k;
-                  HIDE_UNIFORM(iv);
-                  const DTri Tv = A.tris_g[iv];
-                  tri_test(Tv, first + k, lanes & bb_m);
-                } else {
-                  tri_test(A.tris[first + k], first + k, lanes & bb_m);
-                }
-              }
-            };
-            uint32_t cur = O.bvh_root;
-            if (cur & BVH_LEAF_FLAG) {
-              leaf(cur, bb_m);  // the whole mesh fits one leaf
-            } else {
-              uint32_t stack_v = 0;  // lane k of this VGPR = stack slot k (depth <= BVH_MAX_DEPTH < 64)
-              uint32_t sp = 0;
-              for (;;) {
-                if (STATS) st[1]++;
-                mask_t hl, hr;
-                uint32_t n_left, n_right, n_axis;
-                if (VMEM) {
-                  uint32_t cv = O.node_begin + cur;
-                  HIDE_UNIFORM(cv);
-                  const DNode Nv = A.nodes_g[cv];
-                  hl = box_hits_v(Nv, 0);
-                  hr = box_hits_v(Nv, 1);
-                  n_left = __builtin_amdgcn_readfirstlane(Nv.left);
-                  n_right = __builtin_amdgcn_readfirstlane(Nv.right);
-                  n_axis = __builtin_amdgcn_readfirstlane(Nv.axis);
-                } else {
-                  const CADDR DNode &N = nodes[cur];
-                  box_hits2(N, hl, hr);
-                  n_left = N.left; n_right = N.right; n_axis = N.axis;
-                }
-                // near child first
-                const bool swap = ((neg_bits >> n_axis) & 1u) != 0u;
-                const uint32_t d0 = swap ? n_right : n_left, d1 = swap ? n_left : n_right;
-                const mask_t h0 = swap ? hr : hl, h1 = swap ? hl : hr;
-                uint32_t next = 0xFFFFFFFFu;
-                if (h0 != 0ull) {
-                  if (d0 & BVH_LEAF_FLAG) leaf(d0, h0);
-                  else next = d0;
-                }
-                if (h1 != 0ull && !(ANYHIT && bb_m == 0ull)) {
-                  if (d1 & BVH_LEAF_FLAG) {
-                    // d0's leaf may have pulled `lim` in: lanes whose far box now lies beyond it drop out
-                    leaf(d1, h1);
-                  } else if (next == 0xFFFFFFFFu) {
-                    next = d1;
-                  } else {
-                    // v_writelane_b32: value and lane select are both wave-uniform; gfx9 allows one SGPR
-                    // operand per VALU instruction, so the lane select travels in M0
-                    // (readfirstlane restates that both are wave-uniform; the compiler cannot always prove it)
-                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
-                                 : "+v"(stack_v)
-                                 : "s"(__builtin_amdgcn_readfirstlane(d1)), "s"(__builtin_amdgcn_readfirstlane(sp))
-                                 : "m0");
-                    sp++;
-                  }
-                }
+                tri_test(A.tris[first + k], first + k, lanes & bb_m);
                 if (ANYHIT) {
                   if (bb_m == 0ull) break;
                 }
-                if (next == 0xFFFFFFFFu) {
-                  if (sp == 0) break;
-                  sp--;
-                  next = __builtin_amdgcn_readlane(stack_v, sp);
-                }
-                cur = next;
               }
+#ifdef CTR_TIMING
+              t_leaves += __builtin_readcyclecounter() - t_leaf0;
+#endif
+            };
+            // push one inner child (wave-uniform value and slot: both travel as SGPRs)
+            uint32_t stack_v = 0;  // lane k of this VGPR = stack slot k (at most 3 per level, BVH4_MAX_DEPTH levels)
+            uint32_t sp = 0;
+            auto push = [&](uint32_t d) {
+              stack_v = ctr_writelane(__builtin_amdgcn_readfirstlane(d), __builtin_amdgcn_readfirstlane(sp), stack_v);
+              sp++;
+            };
+            uint32_t cur = 0;  // node 0 is the root (a mesh that fits one leaf has a root with one child)
+#ifdef CTR_TIMING
+            t_w0 = __builtin_readcyclecounter();
+            tm[4] += t_w0 - t_bb;
+#endif
+            for (;;) {
+              if (STATS) st[1]++;
+              const CADDR DNode4 &N = nodes4[cur];
+              mask_t h0, h1, h2, h3;
+              box_hits2(N, 0, h0, h1);
+              box_hits2(N, 2, h2, h3);
+              const uint32_t d0 = N.child[0], d1 = N.child[1], d2 = N.child[2], d3 = N.child[3];
+              const bool rev = ((neg_bits >> N.axis) & 1u) != 0u;  // wave-uniform: far end of the order axis first
+              // which children are hit leaves / hit inner nodes, as 4-bit scalars
+              const uint32_t hit_bits = (h0 != 0ull ? 1u : 0u) | (h1 != 0ull ? 2u : 0u) | (h2 != 0ull ? 4u : 0u) | (h3 != 0ull ? 8u : 0u);
+              const uint32_t leaf_bits = ((d0 >> 31) | ((d1 >> 31) << 1) | ((d2 >> 31) << 2) | ((d3 >> 31) << 3));
+              // ---- hit leaves, nearest first: ONE copy of the triangle code, the child picked by scalar selects ----
+              uint32_t todo = hit_bits & leaf_bits;
+              while (todo != 0u) {
+                const uint32_t c = rev ? 31u - (uint32_t)__builtin_clz(todo) : (uint32_t)__builtin_ctz(todo);
+                todo &= ~(1u << c);
+                const uint32_t d = c == 0u ? d0 : c == 1u ? d1 : c == 2u ? d2 : d3;
+                const mask_t h = c == 0u ? h0 : c == 1u ? h1 : c == 2u ? h2 : h3;
+                leaf(d, h);
+                if (ANYHIT) {
+                  if (bb_m == 0ull) break;
+                }
+              }
+              if (ANYHIT) {
+                if (bb_m == 0ull) break;
+              }
+              // ---- hit inner children: the nearest is visited next, the others wait on the stack, farthest pushed first ----
+              const uint32_t inner = hit_bits & ~leaf_bits;
+              uint32_t next = 0xFFFFFFFFu;
+              if (inner != 0u) {
+                auto take = [&](uint32_t bit, uint32_t d) {
+                  if (inner & bit) {
+                    if (next != 0xFFFFFFFFu) push(next);
+                    next = d;
+                  }
+                };
+                if (rev) { take(1u, d0); take(2u, d1); take(4u, d2); take(8u, d3); }
+                else     { take(8u, d3); take(4u, d2); take(2u, d1); take(1u, d0); }
+              }
+              if (next == 0xFFFFFFFFu) {
+                if (sp == 0) break;
+                sp--;
+                next = __builtin_amdgcn_readlane(stack_v, sp);
+              }
+              cur = next;
             }
           } else {
             for (uint32_t k = 0; k < cnt; ++k) {
@@ -826,8 +880,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
           cand = mt;
           ctri = mk_;
-          TSTAMP(t_mesh1);
-          TACC(1, t_mesh0, t_mesh1);
+#ifdef CTR_TIMING
+          {
+            const unsigned long long t_mesh1 = __builtin_readcyclecounter();
+            if (t_w0 == 0) t_w0 = t_bb;  // linear walk
+            tm[5] += (t_mesh1 - t_w0) - t_leaves;
+            tm[6] += t_leaves;
+          }
+#endif
 
         }
         // ray_cast.hpp:43 — strict <, first object in scene order wins ties
@@ -843,7 +903,6 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     }
     const bool was_hit = bobj >= 0;
     TSTAMP(t_loop1);
-    TACC(0, t_loop0, t_loop1);
 
     // =====================================================================
     // continuation: what did this lane cast the ray for?
@@ -941,6 +1000,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       }
     }
 
+    TSTAMP(t_cont_mid);
+    TACC(7, t_loop1, t_cont_mid);
     if (act == ACT_LIGHT) {
       if (li < A.n_light) {
         // shading.hpp:79-85: direction/distance to light li, shadow ray from *hit
@@ -1039,7 +1100,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       first_trip = false;
     }
     TSTAMP(t_cont1);
-    TACC(2, t_loop1, t_cont1);
+    TACC(8, t_cont_mid, t_cont1);
   }
 #undef STK
 
@@ -1075,8 +1136,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     }
 #ifdef CTR_TIMING
     if (lane == 0) {
-      tm[3] = __builtin_readcyclecounter() - tm_start;
-      for (int q = 0; q < 4; q++) atomicAdd(&sh[10 + q], tm[q]);
+      tm[9] = __builtin_readcyclecounter() - tm_start;
+      for (int q = 0; q < 10; q++) atomicAdd(&sh[4 + q], tm[q]);
     }
 #endif
     if (lane == 0) {
@@ -1233,8 +1294,7 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.n_planes = L.n_planes;
   A.tris = (const CADDR DTri *)L.tris;
   A.nodes = (const CADDR DNode *)L.nodes;
-  A.tris_g = L.tris;
-  A.nodes_g = (const DNode *)L.nodes;
+  A.nodes4 = (const CADDR DNode4 *)L.nodes4;
   A.gnorm = (const CADDR float *)L.gnorm;
   A.lights = (const CADDR DLight *)L.lights;
   A.mats = (const CADDR DMat *)L.mats;
@@ -1254,7 +1314,9 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.frames = (uint32_t)(L.bounces > 0 ? L.bounces : 1);
   A.order = (const CADDR uint32_t *)L.order;
   A.cost = L.cost;
-  const size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
+  size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
+  // diagnostic only: extra dynamic LDS per workgroup caps the waves resident per CU (occupancy sweeps)
+  if (const char *pad = getenv("CUTRACE_LDS_PAD")) lds_bytes += (size_t)atol(pad);
   const uint64_t waves = launch_waves(L);
   if (waves > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
   if (waves == 0) return 0;
@@ -1294,14 +1356,5 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
   if (L.variant & KV_STATS)
     return (L.variant & KV_ANYHIT) ? launch<KV_BVH | KV_PREFILTER | KV_ANYHIT | KV_FASTPOW | KV_STATS>(L, s)
                                    : launch<KV_BVH | KV_PREFILTER | KV_FASTPOW | KV_STATS>(L, s);
-  if ((L.variant & KV_VMEM) && (L.variant & KV_BVH) && (L.variant & KV_PREFILTER)) {
-    constexpr uint32_t B = KV_VMEM | KV_BVH | KV_PREFILTER;
-    switch (L.variant & (KV_ANYHIT | KV_FASTPOW)) {
-      case 0: return launch<B>(L, s);
-      case KV_ANYHIT: return launch<B | KV_ANYHIT>(L, s);
-      case KV_FASTPOW: return launch<B | KV_FASTPOW>(L, s);
-      default: return launch<B | KV_ANYHIT | KV_FASTPOW>(L, s);
-    }
-  }
   return (L.variant & KV_FASTPOW) ? launch_main<KV_FASTPOW>(L, s) : launch_main<0>(L, s);
 }

@@ -9,7 +9,8 @@
 //                           per mesh in BVH-leaf order, each carrying its ORIGINAL file
 //                           index (ties on t are broken by it, so results do not depend
 //                           on the order); then stand-alone triangles
-//   DNode  nodes[n_node]    64 B records, per-mesh BVH, inner nodes holding both children's boxes (bvh.h)
+//   DNode4 nodes4[n_node4]  128 B records, per-mesh four-wide BVH, nodes holding their children's boxes (bvh.h)
+//   DNode  nodes[n_node]    64 B records, two-wide tree over the meshes' boxes
 //   float4 gnorm[n_tri]     geometric normal of each DTri as the reference computes it on
 //                           a hit; only the winning triangle's is ever fetched
 //   DLight lights[n_light]  32 B
@@ -43,9 +44,9 @@ struct DObj {
   uint32_t mat;         // material index
   uint32_t tri_begin;   // mesh: first DTri; triangle: its DTri
   uint32_t tri_count;   // mesh: number of triangles; triangle: 1
-  uint32_t node_begin;  // mesh: first DNode of its BVH
-  uint32_t node_count;  // mesh: number of (inner) BVH nodes
-  uint32_t bvh_root;    // mesh: descriptor of the root (bvh.h)
+  uint32_t node_begin;  // mesh: first DNode4 of its BVH (= its root)
+  uint32_t node_count;  // mesh: number of BVH nodes
+  uint32_t bvh_root;    // unused (the root is node 0)
   uint32_t index;       // position in the scene's object list (hit_id; ties on t go to the lower index)
   // triangle: unused
   // mesh    : f[0..2] bbox.min, f[3..5] bbox.max
@@ -99,7 +100,6 @@ enum : uint32_t {
   KV_BVH = 8u,         // walk each mesh through its BVH instead of linearly
   KV_STATS = 16u,      // diagnostic: wave-level work counters into counters[4..9]
   KV_FASTPOW = 32u,    // specular pow() as exp2(e*log2(x)) in f32 instead of f64 pow
-  KV_VMEM = 64u,       // mesh data through the vector memory path instead of the scalar cache
 };
 
 struct DRows {
@@ -121,7 +121,8 @@ struct RenderLaunch {
   const DPlanePair *planes;  // ceil(n_planes / 2) records
   uint32_t n_oloop, n_planes;
   const DTri *tris;
-  const void *nodes;    // DNode[] (bvh.h)
+  const void *nodes;    // DNode[] (bvh.h): top-level tree over the meshes
+  const void *nodes4;   // DNode4[] (bvh.h): per-mesh trees
   const float *gnorm;   // 4 floats per triangle
   const DLight *lights;
   const DMat *mats;
