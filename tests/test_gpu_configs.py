@@ -99,7 +99,7 @@ def test_axis_parallel_rays_through_meshes(ca):
     assert s.ok
     o = oracle.oracle_render(s, bounces=4, threads=NT)
     ds = ca.DeviceScene(s)
-    for variant in (ca.VAR_EXACT_POW, ca.VAR_EXACT_POW | ca.VAR_NO_CLUSTER, ca.0):
+    for variant in (ca.VAR_EXACT_POW, ca.VAR_EXACT_POW | ca.VAR_NO_CLUSTER, 0):
         ds.set_variant(variant)
         r = ds.render(bounces=4)
         assert_parity(r, o, what=f"axis-parallel variant {variant}")
