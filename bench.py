@@ -13,11 +13,16 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   rays    = ray_cast invocations the REFERENCE algorithm performs (incl. its duplicated primary
             cast), the fixed numerator SURVEY.md §8(d) defines; counted by the kernel itself and
             equal to the oracle's count (64 278 888 for the default workload; tested).
-  roofline= algorithmic bytes per launch (56 B x objects per ray_cast + 48 B x
-            triangles of every mesh whose AABB the ray hits + 28 B per pixel) / mean kernel
-            duration from HIP events on the launch stream, against 8 TB/s HBM.  NOTE the kernel
-            is VALU-bound, not HBM-bound: the scene (<1 MB) is served from scalar cache/L2, so
-            the algorithmic figure exceeds what HBM actually carries.
+  roofline= the bound that binds this kernel is VALU ISSUE (the scene, <1 MB, lives in scalar cache / L2;
+            HBM carries 0.006 of its peak):  achieved = wave-level VALU instructions per launch (PMC
+            SQ_INSTS_VALU of the same command, profiles/r02/counters.json) x the mean issue cost of the
+            kernel's instruction mix (profiles/r02/valu_mix.json: static mix of the shipped ISA priced with
+            the per-kind costs MEASURED on the box by scripts/valu_issue.hip — 2.2 cycles VGPR-only, 4.1
+            with an SGPR operand / compare / packed / min3, 8.1 transcendental) / the kernel's mean
+            duration from HIP events in this run;  peak = 1024 SIMDs x the effective shader clock of the PMC
+            pass (GRBM_GUI_ACTIVE / 8 / kernel time).  frac = achieved / peak <= 1.  The HBM view (counter
+            traffic / time / 8 TB/s) is kept as roofline.hbm_frac; SURVEY §8(d)'s "bytes the reference's
+            flat traversal streams" is a property of the workload, reported in config, not a rate.
   cpu_baseline = the CPU checker (oracle/_ref = the reference's own headers built for the host
             when present, else the plain-C port) on a bounded row sample of the same workload.
 """
@@ -53,7 +58,9 @@ def parse_args():
     p.add_argument("--cpu-sample-div", type=int, default=0, help="CPU baseline renders 1/div of the row blocks (0=auto)")
     p.add_argument("--of", type=int, default=0, help="diagnostic: time the tiled batch render of one rank of N (no gather)")
     p.add_argument("--as-rank", type=int, default=0)
-    p.add_argument("--traffic-json", default="", help="optional JSON with PMC-derived HBM bytes per launch")
+    p.add_argument("--counters-json", default="", help="PMC-derived per-launch counters (default profiles/r02/counters.json)")
+    p.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (first launch, host-buffer "
+                   "call, lane statistics, dense mesh): profiling runs")
     return p.parse_args()
 
 
@@ -97,6 +104,58 @@ def cpu_baseline(ca, host_scene, bounces, div):
                        "sample": f"every {div * threads}th 8-row block ({r1['depth'].shape[0]} rows, "
                                  f"{r1['ray_count']} rays) in {dt1:.2f} s"},
     }
+
+
+def extras(ca, hs, args, ds):
+    """Untimed side measurements reported in `config` (never part of `value`)."""
+    import statistics
+    import tempfile
+    from cutrace_amd import scenes
+    w, h = hs.size
+    out = {}
+    # (1) what the drop-in `cutrace <scene.json>` gets (main.cu:30: one frame per process): the FIRST launch of the
+    #     shape on a fresh scene handle, in image order, and the whole host-buffer call (kernel + one D2H of the
+    #     58 MB frame into page-locked memory = the reference's total_ms, kernel.hpp:88,126)
+    fresh = ca.DeviceScene(hs, device=ds.device)
+    fresh.render(bounces=args.bounces, rows=(0, 8), pinned=True)   # another shape: code object + clocks warm
+    r = fresh.render(bounces=args.bounces, pinned=True)
+    out["first_launch_kernel_ms"] = r["kernel_ms"]
+    out["first_launch_total_ms"] = r["total_ms"]
+    for _ in range(3):
+        fresh.render(bounces=args.bounces, pinned=True)
+    rr = [fresh.render(bounces=args.bounces, pinned=True) for _ in range(5)]
+    out["host_call_total_ms_pinned"] = statistics.median(x["total_ms"] for x in rr)
+    out["host_call_total_ms_pageable"] = statistics.median(fresh.render(bounces=args.bounces)["total_ms"] for _ in range(3))
+    # (2) how many of a wave's 64 lanes the wave-level work serves (CTR_VAR_STATS build of the same kernel)
+    fresh.set_variant(ca.VAR_STATS)
+    fresh.render(bounces=args.bounces)
+    c = [int(x) for x in fresh.last_counters()]
+    if c[5] and c[6] and c[7]:
+        out["work_per_launch"] = {"wave_casts": c[4], "bvh_nodes": c[5], "tri_prefilters": c[6], "tri_exact": c[7],
+                                  "mesh_entries": c[8]}
+        out["lane_usefulness"] = {"cast": c[9] / (64.0 * c[4]), "bvh_node": c[10] / (64.0 * c[5]),
+                                  "tri_prefilter": c[11] / (64.0 * c[6]), "tri_exact": c[12] / (64.0 * c[7])}
+    fresh.close()
+    # (3) BASELINE.json words C2 as "~70k tris"; scene/bunny.stl holds 1000.  The same mesh subdivided to 64 000
+    #     triangles (same surface, same 64 278 888 rays): steady-state and first-launch kernel ms
+    if os.path.basename(args.scene) == "bunny.json":
+        d = tempfile.mkdtemp()
+        dense = ca.HostScene.load(scenes.make_dense_bunny(d, 3, width=w, height=h))
+        dd = ca.DeviceScene(dense, device=ds.device)
+        dd.render(bounces=args.bounces, rows=(0, 8))
+        first = dd.render(bounces=args.bounces)
+        for _ in range(3):
+            dd.render(bounces=args.bounces)
+        out["dense_64k_ms"] = statistics.median(dd.render(bounces=args.bounces)["kernel_ms"] for _ in range(7))
+        out["dense_64k_first_launch_ms"] = first["kernel_ms"]
+        out["dense_64k_rays"] = first["ray_count"]
+        dd.close()
+    # (4) SURVEY §8(d): bytes the REFERENCE's flat traversal streams for this frame (56 B x objects per ray_cast +
+    #     48 B x triangles of every mesh whose AABB the ray hits + 28 B per pixel) — a workload property
+    alg_bytes, alg_rays = ds.algorithmic_bytes(bounces=args.bounces)
+    out["reference_equivalent_bytes_per_frame"] = alg_bytes
+    out["reference_rays_per_frame"] = alg_rays
+    return out
 
 
 def main():
@@ -237,43 +296,50 @@ def main():
     if rank == 0:
         total_rays = rays_step * args.steps
         value = total_rays / dt_max / 1e6
-        # ---- roofline of the dominant (only) kernel, per launch ----
-        alg_bytes, alg_rays = ds.algorithmic_bytes(bounces=args.bounces, rows=tiler.rows)
-        alg_bytes, alg_rays = alg_bytes * frames, alg_rays * frames  # one launch renders `frames` frames
-        achieved = alg_bytes / (kern_avg * 1e-3) / 1e9 if kern_avg > 0 else 0.0
-        traffic = None
-        valu_insts = None
-        tj = args.traffic_json or os.path.join(ROOT, "profiles", "traffic.json")
-        if world == 1 and os.path.exists(tj):
-            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # separate runs, gfx950 correction applied by scripts/pmc_traffic.py); same workload only
-            t_ = json.load(open(tj))
-            if t_.get("workload") == f"{os.path.basename(args.scene)}@{w}x{h}b{args.bounces}":
-                traffic = t_.get("hbm_bytes_per_launch")
-                valu_insts = t_.get("valu_insts_per_launch")
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "render_kernel",
-                "kernel_ms_avg": kern_avg, "algorithmic_bytes_per_launch": alg_bytes,
-                "rays_per_launch": alg_rays,
-                "note": "VALU-bound kernel: scene is cache-resident, algorithmic bytes are what the "
-                        "reference's flat traversal streams per ray, not HBM traffic"}
-        if valu_insts and kern_avg > 0:
-            # the bound that actually binds: wave-level VALU instructions (PMC SQ_INSTS_VALU of the same
-            # workload) x 4 issue cycles over 1024 SIMDs x kernel time at the 2.4 GHz engine clock
-            roof["valu_issue_busy"] = valu_insts * 4.0 / (1024.0 * kern_avg * 1e-3 * 2.4e9)
+        workload = f"{os.path.basename(args.scene)}@{w}x{h}b{args.bounces}"
+        # ---- roofline of the dominant (only) kernel, per launch: VALU issue ----
+        cj = args.counters_json or os.path.join(ROOT, "profiles", "r02", "counters.json")
+        mj = os.path.join(ROOT, "profiles", "r02", "valu_mix.json")
+        cnt = json.load(open(cj)) if os.path.exists(cj) else {}
+        mix = json.load(open(mj)) if os.path.exists(mj) else {}
+        mix = next(iter(mix.values())) if mix else {}
+        roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G SIMD-cycles/s", "frac": None,
+                "traffic": None, "kernel": "render_kernel<BVH|PREFILTER|ANYHIT|FASTPOW>", "kernel_ms_avg": kern_avg}
+        if world == 1 and frames == 1 and cnt.get("workload") == workload and mix and kern_avg > 0:
+            cost = mix["mean_issue_cycles"]
+            clock = cnt["effective_clock_ghz"]
+            achieved = cnt["valu_insts_per_launch"] * cost / (kern_avg * 1e-3) / 1e9
+            peak = 1024.0 * clock
+            traffic = cnt.get("hbm_bytes_per_launch")
+            roof.update({
+                "achieved": achieved, "peak": peak, "frac": achieved / peak, "traffic": traffic,
+                "valu_insts_per_launch": cnt["valu_insts_per_launch"], "salu_insts_per_launch": cnt.get("salu_insts_per_launch"),
+                "smem_insts_per_launch": cnt.get("smem_insts_per_launch"),
+                "mean_issue_cycles_per_valu": cost, "valu_mix_static": {k: mix[k] for k in ("F", "H", "Q")},
+                "issue_cost_cycles": {"F_vgpr_only": 2.2, "H_sgpr_operand_cmp_packed_min3": 4.1, "Q_transcendental": 8.1},
+                "effective_clock_ghz": clock, "simds": 1024,
+                "frac_if_every_valu_cost_2.2": cnt["valu_insts_per_launch"] * 2.2 / (kern_avg * 1e-3) / 1e9 / peak,
+                "frac_if_every_valu_cost_4.1": cnt["valu_insts_per_launch"] * 4.1 / (kern_avg * 1e-3) / 1e9 / peak,
+                "hbm_frac": (traffic / (kern_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "hbm_peak_gbs": HBM_PEAK_GBS,
+                "source": "profiles/r02/counters.json (rocprofv3 --pmc passes of this command), profiles/r02/valu_mix.json, "
+                          "profiles/r02/valu_issue.txt"})
+        config = {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
+                              f"{frames} frame(s)/step row-tiled over {world} GPU(s), gather to rank 0",
+                  "tile_order": "expensive tiles first, costs recorded by the previous launch of the same "
+                                "shape (first launch of a shape: image order)",
+                  "kernel_ms_image_order": kern_io,
+                  "frames_per_step": frames, "rays_per_step": rays_step,
+                  "frame_ms": dt_max / args.steps * 1e3 / frames,
+                  "unique_mrays_per_s": (rays_step - frames * w * h) * args.steps / dt_max / 1e6}
+        if world == 1 and not args.no_extras:
+            config.update(extras(ca, hs, args, ds))
         out = {
             "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
-                                   f"{frames} frame(s)/step row-tiled over {world} GPU(s), gather to rank 0",
-                       "tile_order": "expensive tiles first, costs recorded by the previous launch of the same "
-                                     "shape (first launch of a shape: image order)",
-                       "kernel_ms_image_order": kern_io,
-                       "frames_per_step": frames, "rays_per_step": rays_step,
-                       "frame_ms": dt_max / args.steps * 1e3 / frames,
-                       "unique_mrays_per_s": (rays_step - frames * w * h) * args.steps / dt_max / 1e6},
+            "config": config,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

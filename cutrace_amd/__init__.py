@@ -16,14 +16,11 @@ from ._lib import Camera, Light, Material, Object, RenderStats, Rows, SceneDesc,
 ROOT = _lib.ROOT
 
 VAR_AUTO = 0
-VAR_TRI_LDS = 1
 VAR_NO_PREFILTER = 2
 VAR_NO_ANYHIT = 4
 VAR_NO_CLUSTER = 8
 VAR_STATS = 16
 VAR_EXACT_POW = 32
-VAR_VMEM = 64
-VAR_SMEM = 128
 VAR_NO_REORDER = 256
 
 
@@ -143,14 +140,38 @@ class DeviceScene:
             raise RuntimeError("ctr_scene_set_size failed")
         self.w, self.h = w, h
 
-    def render(self, fudge=1e-3, bounces=5, rows=None):
-        """Host-buffer form (ctr_render): returns numpy buffers + stats."""
+    def _pinned_frame(self, px):
+        """One page-locked block for a frame's three buffers (ctr_frame_alloc), kept with the scene handle."""
+        if getattr(self, "_pin_px", 0) < px:
+            self._free_pinned()
+            d, c, n = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+            st = _lib.hip_lib().ctr_frame_alloc(px, C.byref(d), C.byref(c), C.byref(n))
+            if st:
+                raise RuntimeError("ctr_frame_alloc failed")
+            self._pin, self._pin_px = d, px
+        return np.ctypeslib.as_array(self._pin, shape=(7 * self._pin_px,))
+
+    def _free_pinned(self):
+        if getattr(self, "_pin_px", 0):
+            _lib.hip_lib().ctr_frame_free(self._pin)
+            self._pin_px = 0
+
+    def render(self, fudge=1e-3, bounces=5, rows=None, pinned=False):
+        """Host-buffer form (ctr_render): returns numpy buffers + stats.  pinned=True: the buffers are views of
+        the scene handle's page-locked frame block (valid until the next pinned render / close)."""
         L = _lib.hip_lib()
         r = make_rows(self.h, rows)
         n = rows_count(self.h, rows)
-        depth = np.empty((n, self.w), np.float32)
-        color = np.empty((n, self.w, 3), np.float32)
-        normal = np.empty((n, self.w, 3), np.float32)
+        if pinned:
+            px = max(n * self.w, 1)
+            blk = self._pinned_frame(px)
+            depth = blk[:px].reshape(n, self.w) if n else np.empty((0, self.w), np.float32)
+            color = blk[px:4 * px].reshape(n, self.w, 3) if n else np.empty((0, self.w, 3), np.float32)
+            normal = blk[4 * px:7 * px].reshape(n, self.w, 3) if n else np.empty((0, self.w, 3), np.float32)
+        else:
+            depth = np.empty((n, self.w), np.float32)
+            color = np.empty((n, self.w, 3), np.float32)
+            normal = np.empty((n, self.w, 3), np.float32)
         stats = RenderStats()
         st = L.ctr_render(self._h, C.c_float(fudge), bounces, C.byref(r), depth.ctypes.data, color.ctypes.data,
                           normal.ctypes.data, C.byref(stats))
@@ -197,8 +218,25 @@ class DeviceScene:
             raise RuntimeError(f"ctr_algorithmic_bytes failed ({st}): {L.ctr_last_error().decode()}")
         return int(b.value), int(n.value)
 
+    def last_counters(self):
+        """The 16 counter words of the last host-form render (ctr_last_counters)."""
+        out = np.zeros(16, np.uint64)
+        _lib.hip_lib().ctr_last_counters(self._h, out.ctypes.data)
+        return out
+
+    def tile_costs(self):
+        """Per-tile cost of the last launch (ctr_tile_costs), as a uint32 array."""
+        L = _lib.hip_lib()
+        n = C.c_uint64()
+        L.ctr_tile_costs(self._h, None, 0, C.byref(n))
+        out = np.zeros(int(n.value), np.uint32)
+        if n.value:
+            L.ctr_tile_costs(self._h, out.ctypes.data, n.value, C.byref(n))
+        return out
+
     def close(self):
         if self._h:
+            self._free_pinned()
             _lib.hip_lib().ctr_scene_destroy(self._h)
             self._h = None
 

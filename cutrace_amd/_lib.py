@@ -72,7 +72,7 @@ HIP_SYMBOLS = [
     "ctr_abi_version", "ctr_last_error", "ctr_device_count", "ctr_scene_create", "ctr_scene_destroy",
     "ctr_scene_size", "ctr_scene_set_size", "ctr_render", "ctr_render_device", "ctr_set_variant",
     "ctr_scene_set_cameras", "ctr_render_device_batch",
-    "ctr_algorithmic_bytes",
+    "ctr_algorithmic_bytes", "ctr_frame_alloc", "ctr_frame_free", "ctr_tile_costs", "ctr_last_counters",
 ]
 
 _host = None
@@ -137,5 +137,11 @@ def hip_lib():
                                               C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ctr_algorithmic_bytes.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]
+        L.ctr_frame_alloc.argtypes = [C.c_uint64, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
+                                      C.POINTER(C.POINTER(C.c_float))]
+        L.ctr_frame_free.argtypes = [C.POINTER(C.c_float)]
+        L.ctr_frame_free.restype = None
+        L.ctr_last_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.ctr_tile_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         _hip = L
     return _hip

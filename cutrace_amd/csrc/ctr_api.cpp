@@ -117,8 +117,11 @@ struct ctr_scene {
   DCam *d_cams = nullptr;     // device camera array (>= 1 entry)
   uint32_t n_cams = 0;
   uint32_t user_variant = CTR_VAR_AUTO;
-  // cached device outputs for the host-buffer form
-  float *d_depth = nullptr, *d_color = nullptr, *d_normal = nullptr;
+  // cached device outputs for the host-buffer form: ONE allocation, a call's buffers are its consecutive
+  // parts [depth px | color 3 px | normal 3 px] so that a frame can leave in a single D2H transfer
+  float *d_out = nullptr;
+  unsigned long long *h_counters = nullptr;  // pinned landing zone of the 16 counter words
+  unsigned long long last_cnt[16] = {0};     // the counter words of the last host-form render
   unsigned long long *d_counters = nullptr;
   unsigned long long *d_shards = nullptr;  // CTR_SHARDS x CTR_SHARD_WORDS, zero between launches
   size_t out_px = 0;
@@ -141,8 +144,8 @@ struct ctr_scene {
     if (all_opaque && !(user_variant & CTR_VAR_NO_ANYHIT) && !count) kv |= KV_ANYHIT;
     if (!(user_variant & CTR_VAR_NO_CLUSTER) && !count) kv |= KV_BVH;
     if (!(user_variant & CTR_VAR_EXACT_POW)) kv |= KV_FASTPOW;
-    if (count) kv = KV_PREFILTER | KV_COUNT;  // the counting launch walks like the reference
-    if (user_variant & CTR_VAR_STATS) kv = KV_STATS | (all_opaque ? KV_ANYHIT : 0u);
+    if (user_variant & CTR_VAR_STATS) kv = KV_STATS | (all_opaque && !(user_variant & CTR_VAR_NO_ANYHIT) ? KV_ANYHIT : 0u);
+    if (count) kv = KV_PREFILTER | KV_COUNT;  // the counting launch walks like the reference (and wins over STATS)
     return kv;
   }
 };
@@ -241,6 +244,10 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
                            ((uint64_t)L.rows.block_rows << 32) | L.rows.n_parts,
                            ((uint64_t)L.rows.part << 32) | L.rows.part_stride, L.n_frames};
   const bool same = s->order_valid && memcmp(key, s->order_key, sizeof(key)) == 0;
+  // (a shape's first launch runs in image order: an a-priori estimate — tiles whose primary rays meet the box
+  //  of a mesh / sphere, computed and sorted by a pre-pass — was built and measured in round 2: the expensive
+  //  tiles of these scenes are speckle along shadow edges and reflections, not the tiles that look at an
+  //  object, and the pre-pass cost more than it won; DESIGN.md "First launch")
   if (same) L.order = s->d_order; else s->order_age = 0;
   memcpy(s->order_key, key, sizeof(key));
   s->order_valid = true;  // after this launch d_order holds an order measured on this shape
@@ -266,15 +273,24 @@ int check_args(const ctr_scene *s, int bounces) {
 }
 
 int ensure_outputs(ctr_scene *s, size_t px) {
-  if (px <= s->out_px && s->d_depth) return CTR_OK;
-  if (s->d_depth) { (void)hipFree(s->d_depth); (void)hipFree(s->d_color); (void)hipFree(s->d_normal); }
-  s->d_depth = s->d_color = s->d_normal = nullptr;
+  if (!s->h_counters) HIP_TRY(hipHostMalloc((void **)&s->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+  if (px <= s->out_px && s->d_out) return CTR_OK;
+  if (s->d_out) (void)hipFree(s->d_out);
+  s->d_out = nullptr;
   s->out_px = 0;
-  HIP_TRY(hipMalloc((void **)&s->d_depth, sizeof(float) * px));
-  HIP_TRY(hipMalloc((void **)&s->d_color, sizeof(float) * 3 * px));
-  HIP_TRY(hipMalloc((void **)&s->d_normal, sizeof(float) * 3 * px));
+  HIP_TRY(hipMalloc((void **)&s->d_out, sizeof(float) * 7 * px));
   s->out_px = px;
   return CTR_OK;
+}
+
+// is `p` page-locked host memory (hipHostMalloc / hipHostRegister)?  Then a D2H copy is one direct DMA.
+bool is_pinned(const void *p) {
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc'ed memory: "invalid value", not an error of ours
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
 }
 
 }  // namespace
@@ -524,8 +540,9 @@ void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_nodes4, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
-                  (void *)s->d_depth, (void *)s->d_color, (void *)s->d_normal, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
+                  (void *)s->d_out, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
     if (p) (void)hipFree(p);
+  if (s->h_counters) (void)hipHostFree(s->h_counters);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -625,9 +642,9 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   if ((st = ensure_outputs(s, px ? px : 1))) return st;
   L.fudge = fudge;
   L.bounces = bounces;
-  L.depth = s->d_depth;
-  L.color = s->d_color;
-  L.normal = s->d_normal;
+  L.depth = s->d_out;
+  L.color = s->d_out + px;
+  L.normal = s->d_out + 4 * px;
   L.counters = s->d_counters;
   L.variant = s->kernel_variant(count);
   if ((st = attach_order(s, L, count))) return st;
@@ -636,20 +653,36 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   int e = ctr_launch_render(L, nullptr);
   if (e) return hip_fail((hipError_t)e, "render kernel launch");
   HIP_TRY(hipEventRecord(s->ev1, nullptr));
-  HIP_TRY(hipEventSynchronize(s->ev1));
+  // Copy-out (the reference does 3·h row-wise copies, kernel.hpp:110-114).  Page-locked destinations
+  // (ctr_frame_alloc, hipHostMalloc, hipHostRegister) are written by direct DMA queued behind the kernel:
+  // ONE transfer when the three buffers are the consecutive parts of one block, else one per buffer.
+  // Pageable destinations go through the runtime's staged copy, one call per buffer.
+  if (px) {
+    const bool packed = depth && color3 == depth + px && normal3 == color3 + 3 * px;
+    if (packed && is_pinned(depth) && is_pinned(normal3 + 3 * px - 1)) {
+      HIP_TRY(hipMemcpyAsync(depth, s->d_out, sizeof(float) * 7 * px, hipMemcpyDeviceToHost, nullptr));
+    } else {
+      auto out = [&](float *dst, const float *src, size_t n) -> hipError_t {
+        if (!dst) return hipSuccess;
+        if (is_pinned(dst) && is_pinned(dst + n - 1)) return hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost, nullptr);
+        return hipMemcpy(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost);
+      };
+      HIP_TRY(out(depth, L.depth, px));
+      HIP_TRY(out(color3, L.color, 3 * px));
+      HIP_TRY(out(normal3, L.normal, 3 * px));
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-  // one copy per buffer (the reference does 3·h row-wise copies, kernel.hpp:110-114)
-  if (px) {
-    if (depth) HIP_TRY(hipMemcpy(depth, s->d_depth, sizeof(float) * px, hipMemcpyDeviceToHost));
-    if (color3) HIP_TRY(hipMemcpy(color3, s->d_color, sizeof(float) * 3 * px, hipMemcpyDeviceToHost));
-    if (normal3) HIP_TRY(hipMemcpy(normal3, s->d_normal, sizeof(float) * 3 * px, hipMemcpyDeviceToHost));
-  }
-  unsigned long long cnt[16] = {0};
-  HIP_TRY(hipMemcpy(cnt, s->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  unsigned long long cnt[16];
+  memcpy(cnt, s->h_counters, sizeof(cnt));
+  memcpy(s->last_cnt, cnt, sizeof(cnt));
   if (s->user_variant & CTR_VAR_STATS)
     fprintf(stderr, "cutrace_amd stats: wave_casts=%llu nodes=%llu tri_prefilter=%llu tri_exact=%llu mesh_entries=%llu "
-                    "active_lanes=%llu kernel_ms=%.3f\n", cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], cnt[9], ms);
+                    "active_lanes=%llu node_lanes=%llu prefilter_lanes=%llu exact_lanes=%llu kernel_ms=%.3f\n", cnt[4], cnt[5],
+            cnt[6], cnt[7], cnt[8], cnt[9], cnt[10], cnt[11], cnt[12], ms);
   if (aabb_tris) *aabb_tris = cnt[2];
   if (cnt[13] && !(s->user_variant & CTR_VAR_STATS))  // CTR_TIMING diagnostic build: share of the waves' lifetime
     fprintf(stderr, "cutrace_amd timing (%% of wave cycles): cast_setup=%.1f planes=%.1f object_loop=%.1f tlas+aabb=%.1f "
@@ -675,6 +708,40 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
 int ctr_render(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,
                float *normal3, ctr_render_stats *stats) {
   return render_host(s, fudge, bounces, rows, depth, color3, normal3, stats, false, nullptr);
+}
+
+int ctr_last_counters(ctr_scene *s, uint64_t *out16) {
+  if (!s || !out16) return fail(CTR_E_INVALID, "ctr_last_counters: null argument");
+  std::lock_guard<std::mutex> lk(s->mtx);
+  for (int q = 0; q < 16; q++) out16[q] = s->last_cnt[q];
+  return CTR_OK;
+}
+
+int ctr_tile_costs(ctr_scene *s, uint32_t *out, uint64_t capacity, uint64_t *n_tiles) {
+  if (!s) return fail(CTR_E_INVALID, "null scene");
+  std::lock_guard<std::mutex> lk(s->mtx);
+  const uint64_t n = s->order_valid ? s->order_key[0] : 0;
+  if (n_tiles) *n_tiles = n;
+  if (out && n) {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, s->d_cost, sizeof(uint32_t) * (n < capacity ? n : capacity), hipMemcpyDeviceToHost));
+  }
+  return CTR_OK;
+}
+
+int ctr_frame_alloc(uint64_t n_pixels, float **depth, float **color3, float **normal3) {
+  if (!depth || !color3 || !normal3 || n_pixels == 0) return fail(CTR_E_INVALID, "ctr_frame_alloc: bad argument");
+  float *p = nullptr;
+  HIP_TRY(hipHostMalloc((void **)&p, sizeof(float) * 7 * n_pixels, hipHostMallocDefault));
+  *depth = p;
+  *color3 = p + n_pixels;
+  *normal3 = p + 4 * n_pixels;
+  return CTR_OK;
+}
+
+void ctr_frame_free(float *depth) {
+  if (depth) (void)hipHostFree(depth);
 }
 
 int ctr_algorithmic_bytes(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, uint64_t *bytes,

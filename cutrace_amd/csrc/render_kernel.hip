@@ -212,8 +212,10 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
 #endif
   constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
   // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
-  // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast
-  unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+  // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast,
+  // and how many of the 64 lanes had a use for the wave-level work: [6] lanes whose ray meets one of the
+  // visited node's child boxes, [7] lanes inside the leaf's box at a prefilter, [8] lanes in an exact test
+  unsigned long long st[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef CTR_TIMING
   // diagnostic build only: shader-clock stamps per wave -> shards[4..13] = {cast setup, planes, object
   // loop, top-level walk + mesh AABB, mesh entry setup, BVH walk without leaves, leaves, radiance
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
           auto tri_test = [&](const auto &T, uint32_t tri_index, mask_t lanes_m) {
             mask_t c_m = lanes_m;
-            if (STATS) st[2]++;
+            if (STATS) { st[2]++; st[7] += __builtin_popcountll(lanes_m); }
             const float dx = T.px - ro.x, dy = T.py - ro.y, dz = T.pz - ro.z;
             if (PREFILTER) {
               // Conservative reject test.  Same quantities as the exact test
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               }
             }
             if (c_m == 0ull) return;
-            if (STATS) st[3]++;
+            if (STATS) { st[3]++; st[8] += __builtin_popcountll(c_m); }
             bool retire = false;  // any-hit: this lane found its occluder
             if (INVB(c_m)) {
               // ---- triangle::intersect, default_schema.hpp:57-78: the four determinants in the
@@ -828,6 +830,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               mask_t h0, h1, h2, h3;
               box_hits2(N, 0, h0, h1);
               box_hits2(N, 2, h2, h3);
+              if (STATS) st[6] += __builtin_popcountll(h0 | h1 | h2 | h3);
               const uint32_t d0 = N.child[0], d1 = N.child[1], d2 = N.child[2], d3 = N.child[3];
               const bool rev = ((neg_bits >> N.axis) & 1u) != 0u;  // wave-uniform: far end of the order axis first
               // which children are hit leaves / hit inner nodes, as 4-bit scalars
@@ -1132,7 +1135,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     }
     unsigned long long *sh = counters + (size_t)(wave % CTR_SHARDS) * CTR_SHARD_WORDS;
     if (STATS && lane == 0) {
-      for (int q = 0; q < 6; q++) atomicAdd(&sh[4 + q], st[q]);
+      for (int q = 0; q < 9; q++) atomicAdd(&sh[4 + q], st[q]);
     }
 #ifdef CTR_TIMING
     if (lane == 0) {

@@ -24,11 +24,29 @@ inline void render(ctr_scene *scene, size_t bounces, float fudge, float &max, gr
   auto start = std::chrono::high_resolution_clock::now();
   uint64_t w = 0, h = 0;
   ctr_scene_size(scene, &w, &h);
-  depth_map.resize(w, h);   // kernel.hpp:93-95
-  color_map.resize(w, h);
-  normal_map.resize(w, h);
-  ctr_render_stats st{};
   static_assert(sizeof(vector) == 3 * sizeof(float), "grid<vector> must be packed AoS");
+  // kernel.hpp:93-95 resizes the three grids; here they become the three parts of ONE page-locked block
+  // (kept for the life of the process, like the reference's scene memory), so that the frame arrives with a
+  // single direct DMA instead of kernel.hpp:110-114's 3·h row copies through pageable memory
+  static float *frame = nullptr;
+  static uint64_t frame_px = 0;
+  float *fd = nullptr, *fc = nullptr, *fn = nullptr;
+  if (frame_px != w * h) {
+    ctr_frame_free(frame);
+    frame = nullptr;
+    frame_px = 0;
+    if (w * h && ctr_frame_alloc(w * h, &fd, &fc, &fn) == CTR_OK) { frame = fd; frame_px = w * h; }
+  }
+  if (frame) {
+    depth_map.adopt(frame, w, h);
+    color_map.adopt(reinterpret_cast<vector *>(frame + w * h), w, h);
+    normal_map.adopt(reinterpret_cast<vector *>(frame + 4 * w * h), w, h);
+  } else {  // no page-locked memory to be had: ordinary grids, staged copies
+    depth_map.resize(w, h);
+    color_map.resize(w, h);
+    normal_map.resize(w, h);
+  }
+  ctr_render_stats st{};
   ctr_render(scene, fudge, (int)bounces, nullptr, depth_map.data(), &color_map.data()->x, &normal_map.data()->x, &st);
   max = st.max_depth;       // kernel.hpp:120-125 (reduced on the GPU instead of a host scan)
   auto end = std::chrono::high_resolution_clock::now();

@@ -162,10 +162,20 @@ int ctr_scene_set_size(ctr_scene *scene, uint64_t w, uint64_t h);
 int ctr_render(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
                float *depth, float *color3, float *normal3, ctr_render_stats *stats);
 
+/* Page-locked host memory for a frame's three buffers, as the consecutive parts of ONE block
+ * [depth n | color 3n | normal 3n floats]: ctr_render then delivers the frame with a single direct DMA
+ * queued behind the kernel (58 MB at 1080p: ~1.1 ms on PCIe 5) instead of three staged copies through
+ * pageable memory.  Any page-locked destination (hipHostMalloc / hipHostRegister) gets the direct path,
+ * one transfer per buffer.  Replaces the reference's cudaMallocManaged outputs + 3·h row copies
+ * (inc/kernel.hpp:99-118).  Free with ctr_frame_free(depth). */
+int ctr_frame_alloc(uint64_t n_pixels, float **depth, float **color3, float **normal3);
+void ctr_frame_free(float *depth);
+
 /* Device-buffer form: outputs are DEVICE pointers on the scene's device (e.g.
  * torch tensors' data_ptr()), the launch is asynchronous on `hip_stream`
- * (a hipStream_t, NULL = default stream).  No allocation, no sync inside:
- * graph-capturable.  d_counters: optional device pointer to 16×uint64
+ * (a hipStream_t, NULL = default stream).  No sync inside; no allocation
+ * except on the first launch of a shape (tile-order buffers, see "Tile scheduling" below): make that launch
+ * before capturing the call into a HIP graph.  d_counters: optional device pointer to 16×uint64
  * ([0] ray_count, [1] max_depth bits, rest reserved); the call ACCUMULATES into it
  * (add / max), so zero it before the first launch of a frame.  A scene handle keeps one
  * internal reduction scratch: launches of the SAME handle that use counters must be on one
@@ -192,13 +202,10 @@ int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ct
 /* Kernel variant selection (tuning / ablation; default picks the fastest
  * variant that is exact for the scene).  Bits: */
 #define CTR_VAR_AUTO 0u
-#define CTR_VAR_TRI_LDS 1u        /* mesh triangles staged in LDS (else wave-uniform scalar loads) */
 #define CTR_VAR_NO_PREFILTER 2u   /* run the exact Cramer test on every triangle */
 #define CTR_VAR_NO_ANYHIT 4u      /* never use the any-hit shadow early-out */
 #define CTR_VAR_NO_CLUSTER 8u     /* walk meshes linearly instead of through their BVH */
 #define CTR_VAR_EXACT_POW 32u     /* exact specular term: pow() in f64 (<=1 ulp of glibc powf), IEEE half-vector normalisation */
-#define CTR_VAR_VMEM 64u          /* mesh data through the vector memory path (comparison only; scalar is faster) */
-#define CTR_VAR_SMEM 128u         /* force the scalar-cache path (the default) */
 #define CTR_VAR_STATS 16u         /* diagnostic build: print wave-level work counters to stderr */
 #define CTR_VAR_NO_REORDER 256u   /* always dispatch tiles in image order (see below) */
 /* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
@@ -209,6 +216,15 @@ int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ct
  * The first launch of a shape allocates the (small) cost/order buffers with hipMalloc: make that
  * launch before capturing ctr_render_device into a HIP graph, or capture under CTR_VAR_NO_REORDER. */
 int ctr_set_variant(ctr_scene *scene, uint32_t variant_bits);
+/* Diagnostic: the 16 counter words of the last ctr_render on this handle.  [0] ray_count, [1] max-depth
+ * bits; under CTR_VAR_STATS wave-level work: [4] casts (wave trips) [5] BVH nodes visited [6] triangle
+ * prefilters [7] exact triangle tests [8] mesh entries [9] lanes active per cast (sum) [10] lanes whose ray
+ * meets a child box of a visited node (sum) [11] lanes inside the leaf's box per prefilter (sum) [12] lanes
+ * per exact test (sum): [10]/(64*[5]) etc. say how many of a wave's 64 lanes the wave-level work served. */
+int ctr_last_counters(ctr_scene *scene, uint64_t *out16);
+/* Diagnostic: what each 8x8 tile of the last launch cost (shader-clock ticks / 64; tile index = frame-major,
+ * then row-major over the launch's tile grid).  n_tiles receives the count; out may be NULL. */
+int ctr_tile_costs(ctr_scene *scene, uint32_t *out, uint64_t capacity, uint64_t *n_tiles);
 
 /* Algorithmic bytes: 56·n_objects per ray_cast + 48·n_tri for
  * every mesh whose AABB the ray hits + 28 B per pixel, as the reference's flat
