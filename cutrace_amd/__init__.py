@@ -245,3 +245,58 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+
+class MultiScene:
+    """A scene replicated on several GPUs of this process (ctr_multi_create): one frame per call, row-tiled over the
+    devices, gathered to devices[0] (RCCL) and re-interleaved there (ctr_render_multi)."""
+
+    def __init__(self, host_scene, devices):
+        L = _lib.hip_lib()
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        st = L.ctr_multi_create(host_scene.desc, devs, len(devices), C.byref(h))
+        if st:
+            raise RuntimeError(f"ctr_multi_create failed ({st}): {L.ctr_last_error().decode()}")
+        self._h = h
+        self.devices = list(devices)
+        self.w, self.h = host_scene.size
+
+    @property
+    def transport(self):
+        return _lib.hip_lib().ctr_multi_transport(self._h).decode()
+
+    def set_variant(self, bits):
+        _lib.hip_lib().ctr_multi_set_variant(self._h, bits)
+
+    def set_size(self, w, h):
+        if _lib.hip_lib().ctr_multi_set_size(self._h, w, h):
+            raise RuntimeError("ctr_multi_set_size failed")
+        self.w, self.h = w, h
+
+    def render(self, fudge=1e-3, bounces=5, block_rows=8):
+        L = _lib.hip_lib()
+        depth = np.empty((self.h, self.w), np.float32)
+        color = np.empty((self.h, self.w, 3), np.float32)
+        normal = np.empty((self.h, self.w, 3), np.float32)
+        stats = RenderStats()
+        st = L.ctr_render_multi(self._h, C.c_float(fudge), bounces, block_rows, depth.ctypes.data, color.ctypes.data,
+                                normal.ctypes.data, C.byref(stats))
+        if st:
+            raise RuntimeError(f"ctr_render_multi failed ({st})")
+        ms = (C.c_double * len(self.devices))()
+        L.ctr_multi_kernel_ms(self._h, ms, len(self.devices))
+        return dict(depth=depth, color=color, normal=normal, ray_count=int(stats.ray_count), kernel_ms=stats.kernel_ms,
+                    total_ms=stats.total_ms, max_depth=float(stats.max_depth), rows=int(stats.rows),
+                    kernel_ms_per_device=list(ms))
+
+    def close(self):
+        if self._h:
+            _lib.hip_lib().ctr_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -56,6 +56,10 @@ class Rows(C.Structure):
                 ("part", C.c_uint32), ("n_parts", C.c_uint32)]
 
 
+class ReintPart(C.Structure):
+    _fields_ = [("d_depth", C.c_void_p), ("d_color3", C.c_void_p), ("d_normal3", C.c_void_p)]
+
+
 class RenderStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("ray_count", C.c_uint64),
                 ("rows", C.c_uint64), ("max_depth", C.c_float), ("reserved", C.c_uint32)]
@@ -73,6 +77,8 @@ HIP_SYMBOLS = [
     "ctr_scene_size", "ctr_scene_set_size", "ctr_render", "ctr_render_device", "ctr_set_variant",
     "ctr_scene_set_cameras", "ctr_render_device_batch",
     "ctr_algorithmic_bytes", "ctr_frame_alloc", "ctr_frame_free", "ctr_tile_costs", "ctr_last_counters",
+    "ctr_multi_create", "ctr_multi_destroy", "ctr_multi_devices", "ctr_multi_transport", "ctr_multi_size", "ctr_multi_set_size",
+    "ctr_multi_set_variant", "ctr_render_multi", "ctr_multi_kernel_ms", "ctr_reinterleave_device",
 ]
 
 _host = None
@@ -141,6 +147,19 @@ def hip_lib():
                                       C.POINTER(C.POINTER(C.c_float))]
         L.ctr_frame_free.argtypes = [C.POINTER(C.c_float)]
         L.ctr_frame_free.restype = None
+        L.ctr_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.ctr_multi_destroy.argtypes = [C.c_void_p]
+        L.ctr_multi_destroy.restype = None
+        L.ctr_multi_devices.argtypes = [C.c_void_p]
+        L.ctr_multi_transport.argtypes = [C.c_void_p]
+        L.ctr_multi_transport.restype = C.c_char_p
+        L.ctr_multi_set_size.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.ctr_multi_set_variant.argtypes = [C.c_void_p, C.c_uint32]
+        L.ctr_render_multi.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(RenderStats)]
+        L.ctr_reinterleave_device.argtypes = [C.POINTER(ReintPart), C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ctr_multi_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         L.ctr_last_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.ctr_tile_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         _hip = L

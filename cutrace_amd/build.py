@@ -23,7 +23,8 @@ HIP_LIB = os.path.join(PKG, "libcutrace_amd.so")
 CLI = os.path.join(PKG, "cutrace")
 
 HOST_SRCS = [os.path.join(HOST, "scene_host.cpp"), os.path.join(HOST, "images.cpp")]
-HIP_SRCS = [os.path.join(CSRC, "render_kernel.hip"), os.path.join(CSRC, "ctr_api.cpp"), os.path.join(CSRC, "bvh.cpp")]
+HIP_SRCS = [os.path.join(CSRC, "render_kernel.hip"), os.path.join(CSRC, "ctr_api.cpp"), os.path.join(CSRC, "bvh.cpp"),
+            os.path.join(CSRC, "ctr_multi.hip")]
 CLI_SRCS = [os.path.join(HOST, "main.cpp")]
 
 HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I" + INC]
@@ -67,7 +68,7 @@ def build_host(force=False):
 
 def build_hip(force=False):
     if force or not _newer(HIP_LIB, HIP_SRCS):
-        _run([hipcc(), *HIP_FLAGS, "-shared", "-o", HIP_LIB, *HIP_SRCS])
+        _run([hipcc(), *HIP_FLAGS, "-shared", "-o", HIP_LIB, *HIP_SRCS, "-ldl"])
     return HIP_LIB
 
 

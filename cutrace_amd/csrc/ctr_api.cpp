@@ -93,6 +93,8 @@ void make_tri(const ctr_vec3 &p1, const ctr_vec3 &p2, const ctr_vec3 &p3, uint32
 
 }  // namespace
 
+void ctr_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
+
 struct ctr_scene {
   int device = 0;
   DObj *d_objs = nullptr;

@@ -1,0 +1,435 @@
+// ctr_multi.hip — one frame row-tiled over the GPUs of a node, ONE gather to device 0 (include/cutrace_amd.h).
+//
+// The reference is single-GPU (inc/kernel.hpp:86-130 launches one kernel on the current device); this is
+// the multi-device form of the same boundary, SURVEY.md §8(b) item 3 / §8(e): the scene is tiny, so it is
+// replicated on every device; pixels are independent, so device d renders the interleaved row blocks
+// {b : b mod n == d} (contiguous bands are badly balanced) into a compact buffer; the n-1 compact buffers
+// travel to device 0 in ONE grouped RCCL send/recv over xGMI (7 messages on 7 distinct links at n = 8), a
+// HIP kernel re-interleaves the row blocks into the row-major frame, and one D2H delivers it.
+//
+// Single process, one host thread, one stream per device — everything is asynchronous until the final
+// synchronisation.  Built on the PUBLIC per-device entry points (ctr_scene_create, ctr_render_device), so
+// a device's part is rendered by exactly the code the single-GPU path runs: results are bitwise those of
+// ctr_render (tested).  RCCL (librccl.so, 570 MB) is dlopen'ed only when a group of >= 2 distinct devices
+// is created; a group that lists one device several times (rehearsal on a one-GPU box) or a box without
+// RCCL moves the parts with hipMemcpyPeerAsync instead.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "cutrace_amd.h"
+#include "scene_device.h"
+
+namespace {
+
+int mfail(int code, const std::string &msg) {
+  ctr_internal_set_error(msg.c_str());
+  fprintf(stderr, "cutrace_amd: %s\n", msg.c_str());  // print-and-continue, like cudaCheck (inc/cuda.hpp:12-22)
+  return code;
+}
+#define MHIP(expr)                                                                                          \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess) return mfail(CTR_E_HIP_BASE + (int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- RCCL, bound at run time ----
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool load() {
+    if (lib) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) return false;
+    CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+    Send = (decltype(Send))dlsym(lib, "ncclSend");
+    Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+  }
+};
+Rccl g_rccl;
+
+struct Part {         // one device's share of the frame
+  int device = 0;
+  ctr_scene *scene = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float *buf = nullptr;                  // compact [depth px | color 3 px | normal 3 px] on `device`
+  unsigned long long *counters = nullptr;
+  float *gathered = nullptr;             // the same bytes on device 0 (parts >= 1); part 0 reads `buf`
+  uint64_t rows = 0;                     // rows of the current frame this part owns
+  ncclComm_t comm = nullptr;
+};
+
+// sources of the re-interleave: where part p's three compact buffers live on the assembling device
+struct Reint {
+  const float *depth[CTR_MULTI_MAX_DEVICES];
+  const float *color[CTR_MULTI_MAX_DEVICES];
+  const float *normal[CTR_MULTI_MAX_DEVICES];
+  uint32_t n_parts, block_rows, w, h;
+};
+
+// Row y of the frame is local row k of part p:  p = (y / B) % n,  k = (y / B / n) * B + y % B.
+// One workgroup copies one row of all three buffers (7 w floats), 16 bytes per lane where alignment allows.
+__global__ __launch_bounds__(256) void reinterleave_rows(Reint R, float *__restrict__ out_depth, float *__restrict__ out_color,
+                                                         float *__restrict__ out_normal) {
+  const uint32_t y = blockIdx.x;
+  const uint32_t blk = y / R.block_rows, p = blk % R.n_parts;
+  const uint32_t k = (blk / R.n_parts) * R.block_rows + (y % R.block_rows);
+  const float *src3[3] = {R.depth[p] + (size_t)k * R.w, R.color[p] + (size_t)k * R.w * 3, R.normal[p] + (size_t)k * R.w * 3};
+  float *dst3[3] = {out_depth + (size_t)y * R.w, out_color + (size_t)y * R.w * 3, out_normal + (size_t)y * R.w * 3};
+  const uint32_t len3[3] = {R.w, 3 * R.w, 3 * R.w};
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float *a = src3[q];
+    float *b = dst3[q];
+    const uint32_t n = len3[q];
+    if ((((uintptr_t)a | (uintptr_t)b) & 15u) == 0) {
+      const uint32_t n4 = n / 4;
+      for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) ((float4 *)b)[i] = ((const float4 *)a)[i];
+      for (uint32_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) b[i] = a[i];
+    } else {
+      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) b[i] = a[i];
+    }
+  }
+}
+
+uint64_t part_rows(uint64_t h, uint64_t block_rows, uint32_t part, uint32_t n_parts) {
+  uint64_t n = 0;
+  for (uint64_t b = part; b * block_rows < h; b += n_parts) {
+    const uint64_t lo = b * block_rows, hi = lo + block_rows < h ? lo + block_rows : h;
+    n += hi - lo;
+  }
+  return n;
+}
+
+bool pinned(const void *p) {
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
+struct ctr_multi {
+  std::vector<Part> parts;
+  uint64_t w = 0, h = 0;
+  uint64_t cap_px = 0;        // pixels each compact buffer can hold
+  float *frame = nullptr;     // device 0: the re-interleaved frame [depth | color | normal]
+  uint64_t frame_px = 0;
+  unsigned long long *h_counters = nullptr;  // pinned, 16 words per part
+  bool use_rccl = false;
+  std::string transport = "single";
+};
+
+namespace {
+
+int ensure_buffers(ctr_multi *m, uint64_t block_rows) {
+  const uint32_t n = (uint32_t)m->parts.size();
+  uint64_t cap = 0;
+  for (uint32_t p = 0; p < n; p++) {
+    m->parts[p].rows = part_rows(m->h, block_rows, p, n);
+    cap = cap > m->parts[p].rows * m->w ? cap : m->parts[p].rows * m->w;
+  }
+  if (cap == 0) cap = 1;
+  if (cap > m->cap_px) {
+    for (uint32_t p = 0; p < n; p++) {
+      Part &P = m->parts[p];
+      MHIP(hipSetDevice(P.device));
+      if (P.buf) (void)hipFree(P.buf);
+      P.buf = nullptr;
+      MHIP(hipMalloc((void **)&P.buf, sizeof(float) * 7 * cap));
+      if (p > 0) {
+        MHIP(hipSetDevice(m->parts[0].device));
+        if (P.gathered) (void)hipFree(P.gathered);
+        P.gathered = nullptr;
+        MHIP(hipMalloc((void **)&P.gathered, sizeof(float) * 7 * cap));
+      }
+    }
+    m->cap_px = cap;
+  }
+  if (m->w * m->h > m->frame_px) {
+    MHIP(hipSetDevice(m->parts[0].device));
+    if (m->frame) (void)hipFree(m->frame);
+    m->frame = nullptr;
+    MHIP(hipMalloc((void **)&m->frame, sizeof(float) * 7 * m->w * m->h));
+    m->frame_px = m->w * m->h;
+  }
+  return CTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctr_multi_create(const ctr_scene_desc *desc, const int *devices, int n_devices, ctr_multi **out) {
+  if (!desc || !devices || !out || n_devices < 1 || n_devices > CTR_MULTI_MAX_DEVICES)
+    return mfail(CTR_E_INVALID, "ctr_multi_create: bad argument (1.." + std::to_string(CTR_MULTI_MAX_DEVICES) + " devices)");
+  *out = nullptr;
+  auto *m = new ctr_multi();
+  m->w = desc->cam.w;
+  m->h = desc->cam.h;
+  m->parts.resize(n_devices);
+  bool distinct = true;
+  for (int i = 0; i < n_devices; i++)
+    for (int j = 0; j < i; j++)
+      if (devices[i] == devices[j]) distinct = false;
+  for (int i = 0; i < n_devices; i++) {
+    Part &P = m->parts[i];
+    P.device = devices[i];
+    int st = ctr_scene_create(desc, devices[i], &P.scene);  // the scene is replicated: it is < 1 MB
+    if (st) { ctr_multi_destroy(m); return st; }
+    hipError_t e = hipSetDevice(devices[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&P.ev0);
+    if (e == hipSuccess) e = hipEventCreate(&P.ev1);
+    if (e == hipSuccess) e = hipMalloc((void **)&P.counters, 16 * sizeof(unsigned long long));
+    if (e != hipSuccess) { ctr_multi_destroy(m); return mfail(CTR_E_HIP_BASE + (int)e, std::string("ctr_multi_create: ") + hipGetErrorString(e)); }
+  }
+  hipError_t e = hipHostMalloc((void **)&m->h_counters, sizeof(unsigned long long) * 16 * n_devices, hipHostMallocDefault);
+  if (e != hipSuccess) { ctr_multi_destroy(m); return mfail(CTR_E_HIP_BASE + (int)e, "ctr_multi_create: hipHostMalloc"); }
+  if (n_devices > 1) {
+    const char *force = getenv("CUTRACE_MULTI_TRANSPORT");  // "peer" forces hipMemcpyPeerAsync (diagnostic)
+    if (distinct && !(force && !strcmp(force, "peer")) && g_rccl.load()) {
+      std::vector<ncclComm_t> comms(n_devices);
+      ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_devices, devices);
+      if (r == ncclSuccess) {
+        for (int i = 0; i < n_devices; i++) m->parts[i].comm = comms[i];
+        m->use_rccl = true;
+        m->transport = "rccl";
+      } else {
+        mfail(CTR_E_HIP_BASE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r) + " — falling back to peer copies");
+      }
+    }
+    if (!m->use_rccl) {
+      m->transport = "peer-copy";
+      if (distinct) {
+        (void)hipSetDevice(devices[0]);
+        for (int i = 1; i < n_devices; i++) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) {
+            if (hipDeviceEnablePeerAccess(devices[i], 0) != hipSuccess) (void)hipGetLastError();  // already enabled is fine
+          }
+        }
+      }
+    }
+  }
+  *out = m;
+  return CTR_OK;
+}
+
+void ctr_multi_destroy(ctr_multi *m) {
+  if (!m) return;
+  for (Part &P : m->parts) {
+    (void)hipSetDevice(P.device);
+    if (P.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(P.comm);
+    if (P.buf) (void)hipFree(P.buf);
+    if (P.counters) (void)hipFree(P.counters);
+    if (P.ev0) (void)hipEventDestroy(P.ev0);
+    if (P.ev1) (void)hipEventDestroy(P.ev1);
+    if (P.stream) (void)hipStreamDestroy(P.stream);
+    if (P.scene) ctr_scene_destroy(P.scene);
+  }
+  if (!m->parts.empty()) {
+    (void)hipSetDevice(m->parts[0].device);
+    for (Part &P : m->parts)
+      if (P.gathered) (void)hipFree(P.gathered);
+    if (m->frame) (void)hipFree(m->frame);
+  }
+  if (m->h_counters) (void)hipHostFree(m->h_counters);
+  delete m;
+}
+
+int ctr_multi_devices(const ctr_multi *m) { return m ? (int)m->parts.size() : 0; }
+const char *ctr_multi_transport(const ctr_multi *m) { return m ? m->transport.c_str() : ""; }
+
+int ctr_multi_size(const ctr_multi *m, uint64_t *w, uint64_t *h) {
+  if (!m) return mfail(CTR_E_INVALID, "null group");
+  if (w) *w = m->w;
+  if (h) *h = m->h;
+  return CTR_OK;
+}
+
+int ctr_multi_set_size(ctr_multi *m, uint64_t w, uint64_t h) {
+  if (!m) return mfail(CTR_E_INVALID, "null group");
+  for (Part &P : m->parts) {
+    int st = ctr_scene_set_size(P.scene, w, h);
+    if (st) return st;
+  }
+  m->w = w;
+  m->h = h;
+  return CTR_OK;
+}
+
+int ctr_multi_set_variant(ctr_multi *m, uint32_t bits) {
+  if (!m) return mfail(CTR_E_INVALID, "null group");
+  for (Part &P : m->parts) ctr_set_variant(P.scene, bits);
+  return CTR_OK;
+}
+
+int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows, float *depth, float *color3,
+                     float *normal3, ctr_render_stats *stats) {
+  auto t0 = std::chrono::high_resolution_clock::now();
+  if (!m) return mfail(CTR_E_INVALID, "null group");
+  if (block_rows == 0) block_rows = 8;
+  const uint32_t n = (uint32_t)m->parts.size();
+  int st = ensure_buffers(m, block_rows);
+  if (st) return st;
+  const uint64_t w = m->w, h = m->h, fpx = w * h;
+  Part &P0 = m->parts[0];
+  // ---- 1. every device renders its interleaved row blocks into its compact buffer ----
+  for (uint32_t p = 0; p < n; p++) {
+    Part &P = m->parts[p];
+    MHIP(hipSetDevice(P.device));
+    MHIP(hipMemsetAsync(P.counters, 0, 16 * sizeof(unsigned long long), P.stream));
+    MHIP(hipEventRecord(P.ev0, P.stream));
+    const uint64_t px = P.rows * w;
+    if (px) {
+      ctr_rows r{0, h, block_rows, p, n};
+      st = ctr_render_device(P.scene, fudge, bounces, &r, P.buf, P.buf + px, P.buf + 4 * px, P.counters, P.stream);
+      if (st) return st;
+    }
+    MHIP(hipEventRecord(P.ev1, P.stream));
+    MHIP(hipMemcpyAsync(m->h_counters + 16 * p, P.counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, P.stream));
+  }
+  // ---- 2. one gather to device 0 ----
+  if (n > 1) {
+    if (m->use_rccl) {
+      ncclResult_t r = g_rccl.GroupStart();
+      for (uint32_t p = 1; p < n && r == ncclSuccess; p++) {
+        Part &P = m->parts[p];
+        const size_t cnt = (size_t)(7 * P.rows * w);
+        if (!cnt) continue;
+        MHIP(hipSetDevice(P.device));
+        r = g_rccl.Send(P.buf, cnt, ncclFloat, 0, P.comm, P.stream);
+        if (r != ncclSuccess) break;
+        MHIP(hipSetDevice(P0.device));
+        r = g_rccl.Recv(P.gathered, cnt, ncclFloat, (int)p, P0.comm, P0.stream);
+      }
+      ncclResult_t r2 = g_rccl.GroupEnd();
+      if (r == ncclSuccess) r = r2;
+      if (r != ncclSuccess) return mfail(CTR_E_HIP_BASE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r));
+    } else {
+      MHIP(hipSetDevice(P0.device));
+      for (uint32_t p = 1; p < n; p++) {
+        Part &P = m->parts[p];
+        const size_t bytes = sizeof(float) * 7 * P.rows * w;
+        if (!bytes) continue;
+        MHIP(hipStreamWaitEvent(P0.stream, P.ev1, 0));
+        if (P.device == P0.device) MHIP(hipMemcpyAsync(P.gathered, P.buf, bytes, hipMemcpyDeviceToDevice, P0.stream));
+        else MHIP(hipMemcpyPeerAsync(P.gathered, P0.device, P.buf, P.device, bytes, P0.stream));
+      }
+    }
+  }
+  // ---- 3. re-interleave on device 0, 4. one D2H ----
+  MHIP(hipSetDevice(P0.device));
+  const float *result = P0.buf;  // n == 1: the compact buffer IS the frame
+  if (n > 1 && fpx) {
+    Reint R{};
+    for (uint32_t p = 0; p < n; p++) {
+      const float *src = p == 0 ? P0.buf : m->parts[p].gathered;
+      const size_t px = (size_t)(m->parts[p].rows * w);
+      R.depth[p] = src;
+      R.color[p] = src + px;
+      R.normal[p] = src + 4 * px;
+    }
+    R.n_parts = n;
+    R.block_rows = (uint32_t)block_rows;
+    R.w = (uint32_t)w;
+    R.h = (uint32_t)h;
+    hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, P0.stream, R, m->frame, m->frame + fpx, m->frame + 4 * fpx);
+    MHIP(hipGetLastError());
+    result = m->frame;
+  }
+  if (fpx) {
+    const bool packed = depth && color3 == depth + fpx && normal3 == color3 + 3 * fpx;
+    if (packed && pinned(depth) && pinned(normal3 + 3 * fpx - 1)) {
+      MHIP(hipMemcpyAsync(depth, result, sizeof(float) * 7 * fpx, hipMemcpyDeviceToHost, P0.stream));
+    } else {
+      // (hipMemcpyAsync into pageable memory is staged by the runtime and returns when the copy is done)
+      if (depth) MHIP(hipMemcpyAsync(depth, result, sizeof(float) * fpx, hipMemcpyDeviceToHost, P0.stream));
+      if (color3) MHIP(hipMemcpyAsync(color3, result + fpx, sizeof(float) * 3 * fpx, hipMemcpyDeviceToHost, P0.stream));
+      if (normal3) MHIP(hipMemcpyAsync(normal3, result + 4 * fpx, sizeof(float) * 3 * fpx, hipMemcpyDeviceToHost, P0.stream));
+    }
+  }
+  for (uint32_t p = 0; p < n; p++) {
+    MHIP(hipSetDevice(m->parts[p].device));
+    MHIP(hipStreamSynchronize(m->parts[p].stream));
+  }
+  auto t1 = std::chrono::high_resolution_clock::now();
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    uint32_t bits = 0;
+    for (uint32_t p = 0; p < n; p++) {
+      float ms = 0.f;
+      MHIP(hipSetDevice(m->parts[p].device));
+      MHIP(hipEventElapsedTime(&ms, m->parts[p].ev0, m->parts[p].ev1));
+      stats->kernel_ms = stats->kernel_ms > ms ? stats->kernel_ms : ms;  // the slowest device's kernel
+      stats->ray_count += m->h_counters[16 * p + 0];
+      const uint32_t b = (uint32_t)m->h_counters[16 * p + 1];
+      bits = b > bits ? b : bits;
+    }
+    memcpy(&stats->max_depth, &bits, 4);
+    stats->rows = h;
+    stats->total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  }
+  return CTR_OK;
+}
+
+int ctr_reinterleave_device(const ctr_reint_part *parts, uint32_t n_parts, uint64_t block_rows, uint64_t w, uint64_t h,
+                            void *d_depth, void *d_color3, void *d_normal3, void *hip_stream) {
+  if (!parts || n_parts == 0 || n_parts > CTR_MULTI_MAX_DEVICES || block_rows == 0 || !d_depth || !d_color3 || !d_normal3)
+    return mfail(CTR_E_INVALID, "ctr_reinterleave_device: bad argument");
+  if (w == 0 || h == 0) return CTR_OK;
+  if (w > 0x7FFFFFFFull || h > 0x7FFFFFFFull) return mfail(CTR_E_INVALID, "ctr_reinterleave_device: image too large");
+  Reint R{};
+  for (uint32_t p = 0; p < n_parts; p++) {
+    R.depth[p] = (const float *)parts[p].d_depth;
+    R.color[p] = (const float *)parts[p].d_color3;
+    R.normal[p] = (const float *)parts[p].d_normal3;
+  }
+  R.n_parts = n_parts;
+  R.block_rows = (uint32_t)block_rows;
+  R.w = (uint32_t)w;
+  R.h = (uint32_t)h;
+  hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, (hipStream_t)hip_stream, R, (float *)d_depth,
+                     (float *)d_color3, (float *)d_normal3);
+  MHIP(hipGetLastError());
+  return CTR_OK;
+}
+
+int ctr_multi_kernel_ms(ctr_multi *m, double *ms_per_device, int capacity) {
+  if (!m || !ms_per_device) return mfail(CTR_E_INVALID, "ctr_multi_kernel_ms: null argument");
+  for (int p = 0; p < (int)m->parts.size() && p < capacity; p++) {
+    float ms = 0.f;
+    MHIP(hipSetDevice(m->parts[p].device));
+    MHIP(hipEventElapsedTime(&ms, m->parts[p].ev0, m->parts[p].ev1));
+    ms_per_device[p] = ms;
+  }
+  return CTR_OK;
+}
+
+}  // extern "C"

@@ -149,6 +149,8 @@ struct RenderLaunch {
                           // (may alias `order`: written after the render)
 };
 
+// keeps `msg` for ctr_last_error() (ctr_api.cpp); used by the other translation units of the library
+void ctr_internal_set_error(const char *msg);
 // host-callable launcher implemented in render_kernel.hip; returns a hipError_t as int
 int ctr_launch_render(const RenderLaunch &L, void *stream);
 // number of waves (tiles x frames) the launch will dispatch

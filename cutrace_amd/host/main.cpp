@@ -4,9 +4,12 @@
 //
 // Extras (ignored by anything that drives the reference): environment overrides
 //   CUTRACE_BOUNCES, CUTRACE_WIDTH, CUTRACE_HEIGHT, CUTRACE_DEVICE
-// because the reference has no flags (main.cu:8-12) and benchmarking needs them.
+// because the reference has no flags (main.cu:8-12) and benchmarking needs them, and
+//   CUTRACE_DEVICES=N   row-tile the frame over the first N GPUs of the node (ctr_render_multi: one RCCL
+//                       gather to GPU 0, same three files); CUTRACE_DEVICE_LIST=0,2,... names them instead
 #include <cstdlib>
 #include <iostream>
+#include <vector>
 
 #include "cutrace_amd.h"
 #include "cutrace_host.h"
@@ -36,6 +39,41 @@ int main(int argc, const char **argv) {
   if (ow > 0 || oh > 0) {
     ctr_host_scene_set_size(hs, ow > 0 ? (uint64_t)ow : desc->cam.w, oh > 0 ? (uint64_t)oh : desc->cam.h);
     desc = ctr_host_scene_desc(hs);
+  }
+
+  long n_dev = env_long("CUTRACE_DEVICES", 1);
+  std::vector<int> devs;
+  if (const char *list = getenv("CUTRACE_DEVICE_LIST")) {  // explicit list, e.g. "0,2,4,6" (or "0,0": rehearsal on one GPU)
+    for (const char *p = list; *p;) {
+      devs.push_back(atoi(p));
+      while (*p && *p != ',') p++;
+      if (*p == ',') p++;
+    }
+    n_dev = (long)devs.size();
+  } else {
+    for (long i = 0; i < n_dev; i++) devs.push_back((int)i);
+  }
+  if (n_dev > 1) {
+    ctr_multi *group = nullptr;
+    if (ctr_multi_create(desc, devs.data(), (int)n_dev, &group) != CTR_OK) {
+      ctr_host_scene_free(hs);
+      return -3;
+    }
+    ctr_dump_scene(desc);
+    float max_d;
+    cutrace::grid<float> depth_map;
+    cutrace::grid<cutrace::vector> color_map;
+    cutrace::grid<cutrace::vector> normal_map;
+    size_t render, total;
+    cutrace::gpu::render_multi(group, (size_t)env_long("CUTRACE_BOUNCES", 5), 1e-3, max_d, depth_map, color_map, normal_map,
+                               render, total);
+    std::cout << "Render time was " << render << " ms; kernel time with setup/teardown was " << total << " ms.\n";
+    ctr_write_depth_map("./depth_map.jpg", depth_map.data(), depth_map.cols(), depth_map.rows(), max_d);
+    ctr_write_normal_map("./normal_map.jpg", &normal_map.data()->x, normal_map.cols(), normal_map.rows());
+    ctr_write_colorized("./frame.jpg", &color_map.data()->x, color_map.cols(), color_map.rows());
+    ctr_multi_destroy(group);
+    ctr_host_scene_free(hs);
+    return 0;
   }
 
   ctr_scene *scene = nullptr;

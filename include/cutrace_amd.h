@@ -199,6 +199,38 @@ int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ct
                             uint32_t part_stride, void *d_depth, void *d_color3, void *d_normal3,
                             void *d_counters, void *hip_stream);
 
+/* ---- one frame over several GPUs of a node ---------------------------
+ * The reference renders on one device (inc/kernel.hpp:86-130); this is the same boundary for N devices of
+ * ONE process: the scene is replicated (ctr_multi_create uploads it to every listed device), device d
+ * renders the interleaved row blocks {b : b mod N == d} of `block_rows` rows (0 = 8) into a compact buffer,
+ * the N-1 compact buffers reach device 0 (= devices[0]) in ONE grouped RCCL send/recv over xGMI, a HIP
+ * kernel re-interleaves them into the row-major frame, and one D2H delivers it to the caller's buffers
+ * (same layout and semantics as ctr_render; page-locked destinations get direct DMA).  N = 1 needs no RCCL.
+ * librccl.so is loaded on demand; a group that lists the same device more than once (rehearsal on a
+ * one-GPU box), or a box without RCCL, moves the parts with hipMemcpyPeerAsync — ctr_multi_transport tells
+ * which: "single", "rccl" or "peer-copy".  Results are bitwise those of ctr_render on one device.
+ * stats: kernel_ms = the slowest device's kernel, ray_count = sum, max_depth = max, total_ms = wall time. */
+#define CTR_MULTI_MAX_DEVICES 16
+typedef struct ctr_multi ctr_multi;
+int ctr_multi_create(const ctr_scene_desc *desc, const int *devices, int n_devices, ctr_multi **out);
+void ctr_multi_destroy(ctr_multi *group);
+int ctr_multi_devices(const ctr_multi *group);
+const char *ctr_multi_transport(const ctr_multi *group);
+int ctr_multi_size(const ctr_multi *group, uint64_t *w, uint64_t *h);
+int ctr_multi_set_size(ctr_multi *group, uint64_t w, uint64_t h);
+int ctr_multi_set_variant(ctr_multi *group, uint32_t variant_bits);
+int ctr_render_multi(ctr_multi *group, float fudge, int bounces, uint64_t block_rows,
+                     float *depth, float *color3, float *normal3, ctr_render_stats *stats);
+/* The re-interleave step on its own, for callers that gather the parts themselves (one process per GPU with
+ * torch.distributed / RCCL: bench.py): part p's compact buffers (device pointers on the current device) hold
+ * the rows {y : (y / block_rows) % n_parts == p} of a w x h frame in increasing y; they are copied into the
+ * row-major frame buffers.  Asynchronous on hip_stream. */
+typedef struct ctr_reint_part { const void *d_depth, *d_color3, *d_normal3; } ctr_reint_part;
+int ctr_reinterleave_device(const ctr_reint_part *parts, uint32_t n_parts, uint64_t block_rows, uint64_t w, uint64_t h,
+                            void *d_depth, void *d_color3, void *d_normal3, void *hip_stream);
+/* kernel ms of every device in the last ctr_render_multi (load balance) */
+int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
+
 /* Kernel variant selection (tuning / ablation; default picks the fastest
  * variant that is exact for the scene).  Bits: */
 #define CTR_VAR_AUTO 0u

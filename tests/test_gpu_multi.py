@@ -1,0 +1,135 @@
+"""ctr_render_multi (include/cutrace_amd.h): one frame row-tiled over several devices of ONE process, gathered to
+device 0 and re-interleaved by a HIP kernel.  The GPU box has one MI355X, so groups of 2..4 list device 0 several
+times: every part is then rendered by its own scene handle on its own stream and moved with peer copies instead
+of RCCL (RCCL refuses one device twice) — partition, compact buffers, gather targets and the re-interleave kernel
+are exactly what an 8-GPU node runs.  Reference boundary: inc/kernel.hpp:86-130."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import load_scene
+from tests.util import same_bits
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same(a, b):
+    return all(same_bits(a[k], b[k]) for k in ("depth", "color", "normal")) and a["ray_count"] == b["ray_count"] and \
+        a["max_depth"] == b["max_depth"]
+
+
+def test_one_device_group_equals_ctr_render(ca):
+    s = load_scene(ca, "bunny", 256, 144)
+    want = ca.DeviceScene(s).render(bounces=5)
+    m = ca.MultiScene(s, [0])
+    assert m.transport == "single"
+    got = m.render(bounces=5)
+    assert _same(got, want)
+    m.close()
+
+
+@pytest.mark.parametrize("n_dev,w,h,block_rows", [(2, 256, 144, 8), (3, 250, 131, 8), (4, 192, 100, 5), (2, 64, 7, 8), (3, 40, 16, 8)])
+def test_group_on_one_gpu_reassembles_bitwise(ca, n_dev, w, h, block_rows):
+    s = load_scene(ca, "bunny", w, h)
+    want = ca.DeviceScene(s).render(bounces=3)
+    m = ca.MultiScene(s, [0] * n_dev)
+    assert m.transport == "peer-copy"
+    got = m.render(bounces=3, block_rows=block_rows)
+    assert _same(got, want)
+    assert len(got["kernel_ms_per_device"]) == n_dev
+    # a second frame through the same buffers (tile-order feedback active), then another size
+    assert _same(m.render(bounces=3, block_rows=block_rows), want)
+    m.set_size(w - 8, h - 3)
+    s.set_size(w - 8, h - 3)
+    assert _same(m.render(bounces=3, block_rows=block_rows), ca.DeviceScene(s).render(bounces=3))
+    m.close()
+
+
+def test_full_size_group_of_four(ca):
+    """bunny.json@1920x1080, four parts on the one GPU: bitwise the single-device frame, same ray count."""
+    s = load_scene(ca, "bunny")
+    want = ca.DeviceScene(s).render(bounces=5)
+    m = ca.MultiScene(s, [0, 0, 0, 0])
+    got = m.render(bounces=5)
+    assert got["ray_count"] == 64278888
+    assert _same(got, want)
+    m.close()
+
+
+def test_reinterleave_entry_point(ca):
+    """ctr_reinterleave_device on its own (what bench.py's rank 0 calls after the RCCL gather)."""
+    import ctypes as C
+    import torch
+    from cutrace_amd import _lib
+    from cutrace_amd.tiling import part_rows
+    w, h, n, B = 52, 37, 3, 4
+    rng = np.random.default_rng(5)
+    full = {k: rng.standard_normal((h, w) + sh).astype(np.float32) for k, sh in (("depth", ()), ("color", (3,)), ("normal", (3,)))}
+    parts = (_lib.ReintPart * n)()
+    keep = []
+    for p in range(n):
+        rows = part_rows(h, p, n, B)
+        for k, fld in (("depth", "d_depth"), ("color", "d_color3"), ("normal", "d_normal3")):
+            t = torch.from_numpy(np.ascontiguousarray(full[k][rows])).cuda()
+            keep.append(t)
+            setattr(parts[p], fld, t.data_ptr())
+    out = {k: torch.zeros(v.shape, dtype=torch.float32, device="cuda") for k, v in full.items()}
+    st = _lib.hip_lib().ctr_reinterleave_device(parts, n, B, w, h, out["depth"].data_ptr(), out["color"].data_ptr(),
+                                                out["normal"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    for k in full:
+        assert np.array_equal(out[k].cpu().numpy(), full[k])
+
+
+def test_cli_device_list(ca, tmp_path):
+    """`CUTRACE_DEVICE_LIST=0,0 cutrace scene.json`: the multi-device CLI path writes the same three files."""
+    from cutrace_amd import build
+    cli = build.build_cli()
+    env = dict(os.environ, CUTRACE_WIDTH="160", CUTRACE_HEIGHT="90")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    for d, extra in ((one, {}), (two, {"CUTRACE_DEVICE_LIST": "0,0"})):
+        os.symlink(os.path.join(ROOT, "scene"), d / "scene")  # mesh paths are relative to the CWD (schema.md:73-74)
+        r = subprocess.run([cli, "scene/bunny.json"], cwd=d, env=dict(env, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "Render time was " in r.stdout
+    for f in ("frame.jpg", "depth_map.jpg", "normal_map.jpg"):
+        assert (one / f).read_bytes() == (two / f).read_bytes(), f
+
+
+def test_nccl_backend_world_one(ca):
+    """The torch.distributed path of bench.py with the nccl (= RCCL) backend, world size 1: process group, tiler,
+    device-buffer render and the rank-0 hand-over run on the real backend (a one-GPU box cannot hold more ranks)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from cutrace_amd.tiling import FrameTiler
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        s = load_scene(ca, "bunny", 128, 72)
+        ds = ca.DeviceScene(s)
+        tiler = FrameTiler(128, 72, 1, 0, 1, dev)
+        buf = tiler.local[0]
+        d0, c0, n0, _ = tiler.sec
+        esz = buf.element_size()
+        ds.render_device(buf.data_ptr() + d0 * esz, buf.data_ptr() + c0 * esz, buf.data_ptr() + n0 * esz,
+                         stream=torch.cuda.current_stream().cuda_stream, bounces=5)
+        tiler.gather(0)
+        tiler.finish()
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)     # one real RCCL collective on this box
+        dist.barrier()
+        want = ds.render(bounces=5)
+        assert same_bits(tiler.final["depth"][0].cpu().numpy(), want["depth"])
+        assert same_bits(tiler.final["color"][0].cpu().numpy(), want["color"])
+        assert float(t[0]) == 1.0
+    finally:
+        dist.destroy_process_group()

@@ -83,3 +83,24 @@ def test_partition_covers_every_row_once():
             assert max_part_rows(h, n) >= (h + n - 1) // n
     # 1080 rows over 8 ranks in 8-row blocks: 135 blocks -> 17 or 16 blocks per rank
     assert [len(part_rows(1080, p, 8)) for p in range(8)] == [136] * 7 + [128]
+
+
+@pytest.mark.parametrize("h,block_rows,n", [(1080, 8, 8), (4096, 8, 8), (131, 8, 3), (100, 5, 4), (7, 8, 2), (16, 8, 3), (37, 4, 3)])
+def test_row_partition_arithmetic(ca, h, block_rows, n):
+    """The row map of ctr_render_multi's re-interleave kernel (csrc/ctr_multi.hip: p = (y/B) % n,
+    k = (y/B/n)*B + y % B) against the partition ctr_rows defines (host library's ctr_rows_count) and the tiler's."""
+    from cutrace_amd.tiling import part_rows
+    seen = {}
+    for y in range(h):
+        blk = y // block_rows
+        p, k = blk % n, (blk // n) * block_rows + y % block_rows
+        seen.setdefault(p, []).append((k, y))
+    total = 0
+    for p in range(n):
+        rows = part_rows(h, p, n, block_rows)
+        assert ca.rows_count(h, (0, h, block_rows, p, n)) == len(rows)
+        got = seen.get(p, [])
+        assert [y for _, y in got] == rows                 # increasing y
+        assert [k for k, _ in got] == list(range(len(rows)))  # compact local rows 0..len-1
+        total += len(rows)
+    assert total == h
