@@ -143,6 +143,9 @@ def hip_lib():
                                               C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ctr_algorithmic_bytes.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]
+        if not hasattr(L, "ctr_frame_alloc"):  # an older build loaded through CUTRACE_AMD_LIB for A/B timing
+            _hip = L
+            return _hip
         L.ctr_frame_alloc.argtypes = [C.c_uint64, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
                                       C.POINTER(C.POINTER(C.c_float))]
         L.ctr_frame_free.argtypes = [C.POINTER(C.c_float)]

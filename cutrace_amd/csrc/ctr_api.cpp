@@ -122,6 +122,23 @@ struct ctr_scene {
   // cached device outputs for the host-buffer form: ONE allocation, a call's buffers are its consecutive
   // parts [depth px | color 3 px | normal 3 px] so that a frame can leave in a single D2H transfer
   float *d_out = nullptr;
+  // Guard of the BVH culling (see refresh_linear_meshes): host copies of what it needs
+  struct MeshGuard {
+    uint32_t node_begin = 0, node_count = 0;
+    uint32_t tri_begin = 0, tri_count = 0;  // the mesh's DTri range (leaf order); CTR_GUARD_SLOTS spare records follow it
+    uint32_t obj_index = 0;                 // position in d_objs
+    int mesh_pos = -1;                      // position in d_meshes (-1: an empty mesh, never walked)
+    std::vector<double> planes;  // per triangle (leaf order): unit normal (3), a point of the plane (3), extent
+    std::vector<uint32_t> guarded;          // triangles currently copied into the spare records
+    bool linear = false;         // its nodes currently carry unbounded boxes
+  };
+  std::vector<MeshGuard> guards;
+  std::vector<DNode4> h_nodes4;  // the real boxes
+  std::vector<DTri> h_tris;
+  std::vector<float> h_gn;
+  std::vector<DObj> h_objs, h_meshes;
+  std::vector<DCam> h_cams;
+  std::vector<DLight> h_lights;
   unsigned long long *h_counters = nullptr;  // pinned landing zone of the 16 counter words
   unsigned long long last_cnt[16] = {0};     // the counter words of the last host-form render
   unsigned long long *d_counters = nullptr;
@@ -266,6 +283,84 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
   return CTR_OK;
 }
 
+// The per-mesh BVH lets a cast skip triangles whose (widened) box its ray cannot touch.  That is the
+// reference's result except in ONE regime: a ray that lies IN the plane of a triangle to within rounding
+// has alpha = det[a b c] (default_schema.hpp:59) and all three numerators at noise level, and the
+// reference's float test may then accept the triangle for a ray that passes far from it — a hit the
+// culling would drop (tests/test_gpu_parity.py::test_rays_coplanar_with_triangles).  Such a ray has its
+// ORIGIN in the triangle's plane and its direction parallel to it, both to ~1e-6 relative (a direction
+// that leaves the plane by more makes t0 = noise/alpha < min_t): for primary rays the eye must lie in
+// the plane, for shadow rays the light must (or a sun must be parallel to it).  So at upload, and
+// whenever the cameras change, every triangle plane of every mesh is checked against the eyes, the point
+// lights and the sun directions (tolerance 2^-17, an order of magnitude above the rounding that matters), and the
+// triangles that qualify are copied into the mesh's GUARD records, which the walk tests for every lane
+// that passes the mesh's own AABB test, whatever their box (a duplicate test cannot change the
+// lexicographic minimum of (t, file index)).  More than CTR_GUARD_SLOTS of them: every node of the mesh
+// gets unbounded boxes instead — the reference's linear walk through the same code.
+// (Not covered: a secondary ray that falls into a triangle's plane by coincidence of a reflection.)
+#define CTR_GUARD_SLOTS 64u
+int refresh_linear_meshes(ctr_scene *s) {
+  constexpr double TOL = 1.0 / 131072.0;
+  for (ctr_scene::MeshGuard &g : s->guards) {
+    if (g.mesh_pos < 0) continue;
+    std::vector<uint32_t> risky;
+    const size_t nt = g.planes.size() / 7;
+    for (size_t t = 0; t < nt; t++) {
+      const double *q = &g.planes[7 * t];
+      if (q[0] == 0.0 && q[1] == 0.0 && q[2] == 0.0) continue;  // zero-area triangle: alpha is exactly 0, never a hit
+      auto point_in_plane = [&](double x, double y, double z) {
+        const double dx = x - q[3], dy = y - q[4], dz = z - q[5];
+        const double dist = fabs(dx * q[0] + dy * q[1] + dz * q[2]);
+        const double scale = fmax(fmax(fabs(dx), fabs(dy)), fmax(fabs(dz), q[6]));
+        return dist <= TOL * scale;
+      };
+      bool hit = false;
+      for (const DCam &c : s->h_cams)
+        if (point_in_plane(c.pos[0], c.pos[1], c.pos[2])) hit = true;
+      for (const DLight &l : s->h_lights) {
+        if (l.type == CTR_LIGHT_POINT) {
+          if (point_in_plane(l.vx, l.vy, l.vz)) hit = true;
+        } else {
+          const double len = sqrt((double)l.vx * l.vx + (double)l.vy * l.vy + (double)l.vz * l.vz);
+          if (len > 0.0 && fabs(l.vx * q[0] + l.vy * q[1] + l.vz * q[2]) <= TOL * len) hit = true;
+        }
+      }
+      if (hit) risky.push_back((uint32_t)t);
+    }
+    const bool want_linear = risky.size() > CTR_GUARD_SLOTS;
+    if (want_linear) risky.clear();
+    if (want_linear != g.linear && g.node_count) {
+      std::vector<DNode4> nn(s->h_nodes4.begin() + g.node_begin, s->h_nodes4.begin() + g.node_begin + g.node_count);
+      if (want_linear)
+        for (DNode4 &n : nn)
+          for (int c = 0; c < 4; c++)
+            if (n.child[c] != BVH_LEAF_FLAG)  // (an unused slot stays what it is)
+              for (int a = 0; a < 3; a++) { n.lo[a][c] = -3.0e38f; n.hi[a][c] = 3.0e38f; }
+      HIP_TRY(hipMemcpy(s->d_nodes4 + g.node_begin, nn.data(), nn.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+      g.linear = want_linear;
+    }
+    if (risky != g.guarded) {
+      const uint32_t slot0 = g.tri_begin + g.tri_count;
+      for (size_t k = 0; k < risky.size(); k++) {
+        s->h_tris[slot0 + k] = s->h_tris[g.tri_begin + risky[k]];
+        for (int q = 0; q < 4; q++) s->h_gn[4 * (slot0 + k) + q] = s->h_gn[4 * (g.tri_begin + risky[k]) + q];
+      }
+      if (!risky.empty()) {
+        HIP_TRY(hipMemcpy(s->d_tris + slot0, &s->h_tris[slot0], risky.size() * sizeof(DTri), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_gnorm + 4 * (size_t)slot0, &s->h_gn[4 * (size_t)slot0], risky.size() * 4 * sizeof(float), hipMemcpyHostToDevice));
+      }
+      // leaf descriptor of the guard records (relative to the mesh's first triangle), 0 = none
+      const uint32_t desc = risky.empty() ? 0u : (BVH_LEAF_FLAG | ((uint32_t)risky.size() << 24) | g.tri_count);
+      s->h_meshes[g.mesh_pos].bvh_root = desc;
+      s->h_objs[g.obj_index].bvh_root = desc;
+      HIP_TRY(hipMemcpy(s->d_meshes + g.mesh_pos, &s->h_meshes[g.mesh_pos], sizeof(DObj), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(s->d_objs + g.obj_index, &s->h_objs[g.obj_index], sizeof(DObj), hipMemcpyHostToDevice));
+      g.guarded = risky;
+    }
+  }
+  return CTR_OK;
+}
+
 int check_args(const ctr_scene *s, int bounces) {
   if (!s) return fail(CTR_E_INVALID, "null scene");
   if (bounces < 0 || bounces > CTR_MAX_BOUNCES)
@@ -344,6 +439,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   std::vector<DNode> nodes;    // top-level tree
   std::vector<DNode4> nodes4;  // per-mesh trees
   std::vector<float> gn;
+  std::vector<ctr_scene::MeshGuard> guards;
   tris.reserve(d->n_triangles + d->n_objects);
   bool has_mesh = false;
   for (uint64_t i = 0; i < d->n_objects; i++) {
@@ -387,11 +483,36 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         O.node_count = (uint32_t)mnodes.size();
         O.bvh_root = 0;  // node 0 of the mesh; child descriptors stay relative to the mesh's first node / first triangle
         nodes4.insert(nodes4.end(), mnodes.begin(), mnodes.end());
-        tris.resize(tris.size() + n);
+        {
+          ctr_scene::MeshGuard g;
+          g.node_begin = O.node_begin;
+          g.node_count = O.node_count;
+          g.tri_begin = O.tri_begin;
+          g.tri_count = n;
+          g.obj_index = (uint32_t)i;
+          g.planes.resize(7 * (size_t)n);
+          for (uint32_t k = 0; k < n; k++) {
+            const ctr_triangle &t = src[order[k]];  // leaf order, like the DTri records
+            const double ax = (double)t.p2.x - t.p1.x, ay = (double)t.p2.y - t.p1.y, az = (double)t.p2.z - t.p1.z;
+            const double bx = (double)t.p2.x - t.p3.x, by = (double)t.p2.y - t.p3.y, bz = (double)t.p2.z - t.p3.z;
+            double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+            const double len = sqrt(nx * nx + ny * ny + nz * nz);
+            double *q = &g.planes[7 * (size_t)k];
+            if (len > 0.0) { q[0] = nx / len; q[1] = ny / len; q[2] = nz / len; } else { q[0] = q[1] = q[2] = 0.0; }
+            q[3] = t.p2.x; q[4] = t.p2.y; q[5] = t.p2.z;
+            q[6] = fmax(fmax(fmax(fabs(ax), fabs(ay)), fabs(az)), fmax(fmax(fabs(bx), fabs(by)), fabs(bz)));
+          }
+          guards.push_back(std::move(g));
+        }
+        tris.resize(tris.size() + n + (n ? CTR_GUARD_SLOTS : 0u));  // + the mesh's guard records (refresh_linear_meshes)
         gn.resize(4 * tris.size());
         for (uint32_t k = 0; k < n; k++) {
           const ctr_triangle &t = src[order[k]];
           make_tri(t.p1, t.p2, t.p3, order[k], tris[O.tri_begin + k], &gn[4 * (O.tri_begin + k)]);
+        }
+        for (uint32_t k = 0; n && k < CTR_GUARD_SLOTS; k++) {  // unused guard records: copies of the first triangle
+          tris[O.tri_begin + n + k] = tris[O.tri_begin];
+          for (int q = 0; q < 4; q++) gn[4 * (O.tri_begin + n + k) + q] = gn[4 * O.tri_begin + q];
         }
         O.f[0] = o.v0.x; O.f[1] = o.v0.y; O.f[2] = o.v0.z;
         O.f[3] = o.v1.x; O.f[4] = o.v1.y; O.f[5] = o.v1.z;
@@ -449,6 +570,9 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     bvh_build(prims, 1, tnodes, order, tlas_root);
     nodes.insert(nodes.end(), tnodes.begin(), tnodes.end());
     for (uint32_t k : order) meshes.push_back(meshes_in[k]);
+    for (size_t pos = 0; pos < meshes.size(); pos++)
+      for (ctr_scene::MeshGuard &g : guards)
+        if (g.obj_index == meshes[pos].index) g.mesh_pos = (int)pos;
   }
   std::vector<DLight> lights(d->n_lights);
   for (uint64_t i = 0; i < d->n_lights; i++) {
@@ -510,6 +634,18 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     return hip_fail(er, "scene upload");
   }
   s->n_cams = 1;
+  s->guards = std::move(guards);
+  s->h_nodes4 = nodes4;
+  s->h_tris = tris;
+  s->h_gn = gn;
+  s->h_objs = objs;
+  s->h_meshes = meshes;
+  s->h_cams.assign(1, s->cam);
+  s->h_lights = lights;
+  if (int st = refresh_linear_meshes(s)) {
+    ctr_scene_destroy(s);
+    return st;
+  }
   *out = s;
   return CTR_OK;
 }
@@ -535,7 +671,8 @@ int ctr_scene_set_cameras(ctr_scene *s, const ctr_camera *cams, uint32_t n) {
   s->n_cams = n;
   s->cams_epoch++;
   s->cam = dc[0];
-  return CTR_OK;
+  s->h_cams = dc;
+  return refresh_linear_meshes(s);
 }
 
 void ctr_scene_destroy(ctr_scene *s) {

@@ -404,29 +404,33 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         den = (rdx * nx + rdy * ny) + rdz * nz;
       };
       const uint32_t n_pairs = (A.n_planes + 1u) >> 1;
-      for (uint32_t p = 0; p < n_pairs; p += 3) {
-        const uint32_t p1 = p + 1 < n_pairs ? p + 1 : p, p2 = p + 2 < n_pairs ? p + 2 : p;
-        const CADDR DPlanePair &P0 = A.planes[p], &P1 = A.planes[p1], &P2 = A.planes[p2];
-        float2_ num0, den0, num1, den1, num2, den2;
-        num_den(P0, num0, den0);
-        num_den(P1, num1, den1);
-        num_den(P2, num2, den2);
-        const uint32_t i00 = P0.index[0], i01 = P0.index[1], i10 = P1.index[0], i11 = P1.index[1], i20 = P2.index[0],
-                       i21 = P2.index[1];
-        if (!plane_test(i00, num0.x, den0.x)) break;
-        if (i01 != CTR_PLANE_PAD) {
-          if (!plane_test(i01, num0.y, den0.y)) break;
-        }
-        if (p1 != p) {
+      for (uint32_t p = 0; p < n_pairs;) {
+        if (n_pairs - p >= 3u) {
+          const CADDR DPlanePair &P0 = A.planes[p], &P1 = A.planes[p + 1], &P2 = A.planes[p + 2];
+          float2_ num0, den0, num1, den1, num2, den2;
+          num_den(P0, num0, den0);
+          num_den(P1, num1, den1);
+          num_den(P2, num2, den2);
+          const uint32_t i00 = P0.index[0], i01 = P0.index[1], i10 = P1.index[0], i11 = P1.index[1], i20 = P2.index[0],
+                         i21 = P2.index[1];
+          p += 3;
+          if (!plane_test(i00, num0.x, den0.x)) break;
+          if (!plane_test(i01, num0.y, den0.y)) break;   // (only the LAST record of the array can hold a padding slot)
           if (!plane_test(i10, num1.x, den1.x)) break;
-          if (i11 != CTR_PLANE_PAD) {
-            if (!plane_test(i11, num1.y, den1.y)) break;
-          }
-        }
-        if (p2 != p) {
+          if (!plane_test(i11, num1.y, den1.y)) break;
           if (!plane_test(i20, num2.x, den2.x)) break;
           if (i21 != CTR_PLANE_PAD) {
             if (!plane_test(i21, num2.y, den2.y)) break;
+          }
+        } else {
+          const CADDR DPlanePair &P0 = A.planes[p];
+          float2_ num0, den0;
+          num_den(P0, num0, den0);
+          const uint32_t i00 = P0.index[0], i01 = P0.index[1];
+          p += 1;
+          if (!plane_test(i00, num0.x, den0.x)) break;
+          if (i01 != CTR_PLANE_PAD) {
+            if (!plane_test(i01, num0.y, den0.y)) break;
           }
         }
       }
@@ -820,6 +824,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               sp++;
             };
             uint32_t cur = 0;  // node 0 is the root (a mesh that fits one leaf has a root with one child)
+            const uint32_t guard_desc = O.bvh_root;
 #ifdef CTR_TIMING
             t_w0 = __builtin_readcyclecounter();
             tm[4] += t_w0 - t_bb;
@@ -838,11 +843,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               const uint32_t leaf_bits = ((d0 >> 31) | ((d1 >> 31) << 1) | ((d2 >> 31) << 2) | ((d3 >> 31) << 3));
               // ---- hit leaves, nearest first: ONE copy of the triangle code, the child picked by scalar selects ----
               uint32_t todo = hit_bits & leaf_bits;
+              // (pseudo-child 4, at the root only: the mesh's guard records — triangles whose plane contains an
+              //  eye or a light, which must meet every lane whatever their box; almost always none)
+              if (cur == 0u && guard_desc != 0u) todo |= 16u;
               while (todo != 0u) {
                 const uint32_t c = rev ? 31u - (uint32_t)__builtin_clz(todo) : (uint32_t)__builtin_ctz(todo);
                 todo &= ~(1u << c);
-                const uint32_t d = c == 0u ? d0 : c == 1u ? d1 : c == 2u ? d2 : d3;
-                const mask_t h = c == 0u ? h0 : c == 1u ? h1 : c == 2u ? h2 : h3;
+                const uint32_t d = c == 0u ? d0 : c == 1u ? d1 : c == 2u ? d2 : c == 3u ? d3 : guard_desc;
+                const mask_t h = c == 0u ? h0 : c == 1u ? h1 : c == 2u ? h2 : c == 3u ? h3 : bb_m;
                 leaf(d, h);
                 if (ANYHIT) {
                   if (bb_m == 0ull) break;

@@ -46,7 +46,8 @@ struct DObj {
   uint32_t tri_count;   // mesh: number of triangles; triangle: 1
   uint32_t node_begin;  // mesh: first DNode4 of its BVH (= its root)
   uint32_t node_count;  // mesh: number of BVH nodes
-  uint32_t bvh_root;    // unused (the root is node 0)
+  uint32_t bvh_root;    // mesh: leaf descriptor of its GUARD records (triangles every lane that enters the mesh must
+                        // meet, whatever their box; ctr_api.cpp refresh_linear_meshes), 0 = none.  The root is node 0.
   uint32_t index;       // position in the scene's object list (hit_id; ties on t go to the lower index)
   // triangle: unused
   // mesh    : f[0..2] bbox.min, f[3..5] bbox.max

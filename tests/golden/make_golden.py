@@ -30,7 +30,10 @@ SMALL = [
     ("bunny", 96, 54, 5), ("bunny", 64, 36, 0),
     ("mirror", 96, 54, 5), ("mirror", 96, 54, 8),
 ]
-FULL = [("sphere_plane", 1920, 1080, 5), ("mirror", 1920, 1080, 5), ("bunny", 1920, 1080, 5)]
+FULL = [("sphere_plane", 1920, 1080, 5), ("mirror", 1920, 1080, 5), ("bunny", 1920, 1080, 5), ("mirror", 1920, 1080, 8)]
+# C4 (4x4 bunny grid @4096x4096, cutrace_amd/scenes.py:make_bunny_grid): the reference needs minutes per frame on the
+# CPU, so whole rows are stored instead: these rows of the 4096-row frame, every pixel of each
+C4_ROWS = [40, 1111, 2050, 2600, 3000, 3333, 3700, 4000]
 
 
 def sums(r):
@@ -58,8 +61,30 @@ def main():
         print("wrote", path, "casts", r["ray_count"])
     if only_small:
         return
+    if "--no-c4" not in sys.argv:
+        import tempfile
+        from cutrace_amd import scenes
+        d = tempfile.mkdtemp()
+        s = ca.HostScene.load(scenes.make_bunny_grid(d))
+        assert s.ok and s.size == (4096, 4096)
+        out = {}
+        for y in C4_ROWS:
+            r = oracle.ref_render(s, bounces=5, rows=(y, y + 1), threads=THREADS)
+            out[f"depth_{y}"], out[f"color_{y}"], out[f"normal_{y}"] = r["depth"][0], r["color"][0], r["normal"][0]
+            out[f"rays_{y}"] = np.int64(r["ray_count"])
+            print("C4 row", y, "casts", r["ray_count"], flush=True)
+        path = os.path.join(OUT, "rows_bunny_grid4x4_4096x4096_b5.npz")
+        np.savez_compressed(path, rows=np.asarray(C4_ROWS, np.int64), **out)
+        print("wrote", path)
+    if "--only-new" in sys.argv:
+        todo = [t for t in FULL if not os.path.exists(os.path.join(OUT, f"full_{t[0]}_{t[1]}x{t[2]}_b{t[3]}.npz"))]
+    else:
+        todo = FULL
     rng = np.random.RandomState(1234)
     for name, w, h, b in FULL:
+        if (name, w, h, b) not in todo:
+            rng.choice(w * h, 4096, replace=False)  # keep the sample sequence of the fixtures already committed
+            continue
         s = ca.HostScene.load(f"scene/{name}.json")
         assert s.ok and s.size == (w, h)
         r = oracle.ref_render(s, bounces=b, threads=THREADS)

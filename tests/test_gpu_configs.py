@@ -167,3 +167,87 @@ def test_bench_multi_rank_path_on_one_gpu(ca):
     import json
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["frames_per_step"] == 2
+
+
+ALL_OFF = None
+
+
+def _accel_on_off_bitwise(ca, ds, bounces, what):
+    """default kernel (exact pow) vs. BVH, prefilter and any-hit all off: the reference's linear walk"""
+    ds.set_variant(ca.VAR_EXACT_POW)
+    a = ds.render(bounces=bounces)
+    ds.set_variant(ca.VAR_EXACT_POW | ca.VAR_NO_CLUSTER | ca.VAR_NO_PREFILTER | ca.VAR_NO_ANYHIT)
+    b = ds.render(bounces=bounces)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(a[k], b[k]), f"{what}: {k} differs between accelerated and plain walk"
+    assert a["ray_count"] == b["ray_count"] and a["max_depth"] == b["max_depth"]
+    ds.set_variant(0)
+    return a
+
+
+def _check_full_fixture(r, g, w):
+    idx = g["sample_idx"]
+    assert same_bits(r["depth"].reshape(-1)[idx], g["depth"])
+    assert same_bits(r["normal"].reshape(-1, 3)[idx], g["normal"])
+    assert np.abs(r["color"].reshape(-1, 3)[idx].astype(np.float64) - g["color"].astype(np.float64)).max() <= 1e-4
+    assert r["ray_count"] == int(g["ray_count"])
+    assert int(np.isfinite(r["depth"]).sum()) == int(g["n_finite"])
+    fin = np.isfinite(r["depth"])
+    assert abs(float(r["depth"][fin].astype(np.float64).sum()) - float(g["sum_depth"])) < 1e-6 * abs(float(g["sum_depth"]))
+    assert np.allclose(r["normal"].astype(np.float64).reshape(-1, 3).sum(0), g["sum_normal"], rtol=0, atol=1e-6)
+
+
+def test_c3_mirror_1080p_depth_8_full_size(ca):
+    """C3 as BASELINE.json words it (mirror.json@1920x1080, recursion depth 8) at FULL size: against the
+    reference build's fixture (samples, checksums, ray count) and accelerated vs. plain walk, bit for bit."""
+    s = ca.HostScene.load("scene/mirror.json")
+    ds = ca.DeviceScene(s)
+    a = _accel_on_off_bitwise(ca, ds, 8, "mirror@1080p b8")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_mirror_1920x1080_b8.npz"))
+    _check_full_fixture(a, g, 1920)
+    _check_full_fixture(ds.render(bounces=8), g, 1920)   # and the default (fast specular) kernel
+
+
+def test_c3_deep_1080p_depth_8_full_size(ca, gen_dir):
+    """C3-deep (walls reflect 0.5: every path really reaches depth 8) at 1920x1080: accelerated vs. plain walk."""
+    from cutrace_amd import scenes
+    s = ca.HostScene.load(scenes.make_mirror_deep(gen_dir))
+    assert s.size == (1920, 1080)
+    a = _accel_on_off_bitwise(ca, ca.DeviceScene(s), 8, "mirror-deep@1080p b8")
+    assert a["ray_count"] > 20 * 1920 * 1080
+
+
+def test_c2_dense_1080p_full_size(ca, gen_dir):
+    """C2-dense (64 000-triangle bunny) at 1920x1080: accelerated vs. plain walk, bit for bit, same rays as C2."""
+    from cutrace_amd import scenes
+    s = ca.HostScene.load(scenes.make_dense_bunny(gen_dir, rounds=3))
+    assert s.size == (1920, 1080)
+    a = _accel_on_off_bitwise(ca, ca.DeviceScene(s), 5, "dense bunny@1080p")
+    assert a["ray_count"] == 64278888
+
+
+def test_c4_4096_full_size(ca, gen_dir):
+    """C4 (16 meshes, 4096x4096) at FULL size: whole rows against the reference build's fixture, accelerated
+    vs. plain walk bit for bit, and the eight-way row tiling of ctr_render_multi reassembling the same frame."""
+    from cutrace_amd import scenes
+    s = ca.HostScene.load(scenes.make_bunny_grid(gen_dir))
+    assert s.size == (4096, 4096)
+    ds = ca.DeviceScene(s)
+    a = _accel_on_off_bitwise(ca, ds, 5, "C4@4096")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rows_bunny_grid4x4_4096x4096_b5.npz"))
+    for y in [int(v) for v in g["rows"]]:
+        assert same_bits(a["depth"][y], g[f"depth_{y}"]), y
+        assert same_bits(a["normal"][y], g[f"normal_{y}"]), y
+        assert same_bits(a["color"][y], g[f"color_{y}"]), y      # exact-pow kernel: bit for bit
+    assert a["ray_count"] == 4096 * 4096 * 31 == 520093696
+    fast = ds.render(bounces=5)
+    for y in [int(v) for v in g["rows"]]:
+        assert np.abs(fast["color"][y].astype(np.float64) - g[f"color_{y}"].astype(np.float64)).max() <= 1e-4
+    ds.close()
+    m = ca.MultiScene(s, [0] * 8)
+    m.set_variant(ca.VAR_EXACT_POW)
+    t = m.render(bounces=5)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(t[k], a[k]), k
+    assert t["ray_count"] == a["ray_count"]
+    m.close()

@@ -401,3 +401,66 @@ def test_tile_order_is_a_permutation_at_odd_and_large_sizes(gpu, w, h):
         for k in ("depth", "normal", "color"):
             assert same_bits(r[k], ref[k]), (k, i, w, h)
         assert r["ray_count"] == ref["ray_count"]
+
+
+def _coplanar_scene(ca, tmp_path, w, h, row, n_tris, seed):
+    """A mesh whose triangles all lie (to float rounding) in the plane that contains EVERY primary ray of image row
+    `row`: for those rays alpha = det[a b c] of default_schema.hpp:59 is pure rounding noise, and so are beta, gamma
+    and t — the regime in which the reference's float test can report a hit for a ray that passes far from the
+    triangle (BVH caveat)."""
+    import ctypes as C
+    import json
+    from cutrace_amd import _lib, scenes
+    rng = np.random.default_rng(seed)
+    eye, up, look = (0.3, 0.8, 4.0), (0.0, 1.0, 0.0), (-0.05, -0.15, -1.0)
+    cam = _lib.Camera()
+    _lib.host_lib().ctr_camera_look_at(C.byref(cam), _lib.Vec3(*eye), _lib.Vec3(*up), _lib.Vec3(*look))
+    f32 = np.float32
+    E, R, U, F = (np.array(v.tup(), f32) for v in (cam.pos, cam.right, cam.up, cam.forward))
+    v = (f32(0.5) - f32(row) / f32(h)) * U + F           # the row's rays: E + s*right*k + t*v
+    tris = []
+    for _ in range(n_tris):
+        s0, t0 = f32(rng.uniform(-1.2, 1.2)), f32(rng.uniform(2.0, 5.0))
+        pts = []
+        for _ in range(3):
+            s, t = s0 + f32(rng.uniform(-0.25, 0.25)), t0 + f32(rng.uniform(-0.4, 0.4))
+            pts.append((E + s * R + t * v).astype(f32))
+        tris.append(pts)
+    stl = str(tmp_path / f"coplanar_{seed}.stl")
+    scenes.write_stl(stl, np.asarray(tris, f32))
+    sc = {"camera": {"eye": list(eye), "up": list(up), "look": list(look), "near_plane": 0.1, "far_plane": 100.0,
+                     "width": w, "height": h, "ambient": 0.1},
+          "lights": [{"type": "point", "point": [1.5, 2.5, 2.0], "color": [0.8, 0.8, 0.8]},
+                     {"type": "point", "point": [float(E[0] + 0.5 * R[0] + 1.0 * v[0]), float(E[1] + 0.5 * R[1] + 1.0 * v[1]),
+                                                  float(E[2] + 0.5 * R[2] + 1.0 * v[2])]}],   # a light IN the plane too
+          "materials": [{"type": "solid", "color": [0.8, 0.6, 0.3], "specular": 0.4, "reflect": 0.3, "phong": 40},
+                        {"type": "solid", "color": [0.3, 0.5, 0.9], "specular": 0.2, "reflect": 0.2, "phong": 10}],
+          "objects": [{"type": "mesh", "file": stl, "material": 0},
+                      {"type": "plane", "point": [0, -1.0, 0], "normal": [0, 1, 0], "material": 1},
+                      {"type": "plane", "point": [0, 0, -6.0], "normal": [0, 0, 1], "material": 1}]}
+    s = ca.HostScene.parse(json.dumps(sc))
+    assert s.ok
+    return s
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_rays_coplanar_with_triangles(ca, tmp_path, seed):
+    """Adversarial case for the BVH culling: 48 triangles in the plane of image row 12, so
+    that 512 primary rays (and the shadow rays towards the in-plane light) are coplanar with every one of them up to
+    rounding.  The accelerated kernel must still equal the plain linear walk bit for bit and the oracle within the
+    parity bar; the number of pixels of that row whose hit is one of these noise-level triangles is reported."""
+    w, h, row = 512, 24, 12
+    s = _coplanar_scene(ca, tmp_path, w, h, row, 48, seed)
+    o = oracle.oracle_render(s, bounces=2, threads=os.cpu_count() or 4)
+    ds = ca.DeviceScene(s)
+    ds.set_variant(ca.VAR_EXACT_POW)
+    fast = ds.render(bounces=2)
+    ds.set_variant(ca.VAR_EXACT_POW | ca.VAR_NO_CLUSTER | ca.VAR_NO_PREFILTER | ca.VAR_NO_ANYHIT)
+    plain = ds.render(bounces=2)
+    assert_parity(plain, o, what=f"coplanar seed {seed}: plain walk vs oracle")
+    on_mesh = int((o["hit_id"][row] == 0).sum())
+    diff = int((fast["depth"].view(np.uint32) != plain["depth"].view(np.uint32)).sum())
+    print(f"coplanar seed {seed}: {on_mesh} of {w} pixels of row {row} hit the in-plane mesh; accelerated vs plain: {diff} depth values differ")
+    for k in ("depth", "normal", "color"):
+        assert same_bits(fast[k], plain[k]), f"seed {seed}: {k}"
+    assert fast["ray_count"] == plain["ray_count"] == o["ray_count"]

@@ -143,3 +143,38 @@ def test_oracle_matches_reference_build_on_corner_meshes(ca, tmp_path):
                 assert np.array_equal(o[k].view(np.uint32) if o[k].dtype == np.float32 else o[k],
                                       r[k].view(np.uint32) if r[k].dtype == np.float32 else r[k]), (name, fudge, k)
             assert o["ray_count"] == r["ray_count"]
+
+
+def test_oracle_matches_c4_rows_fixture(ca, tmp_path):
+    """C4 (4x4 bunny grid @4096x4096): whole rows rendered by the reference build (tests/golden/make_golden.py)."""
+    from cutrace_amd import scenes
+    g = np.load(os.path.join(GOLD, "rows_bunny_grid4x4_4096x4096_b5.npz"))
+    s = ca.HostScene.load(scenes.make_bunny_grid(str(tmp_path)))
+    assert s.ok and s.size == (4096, 4096)
+    for y in [int(v) for v in g["rows"]][::3]:   # three of the eight rows keep this CPU test to seconds
+        r = oracle.oracle_render(s, bounces=5, rows=(y, y + 1), threads=os.cpu_count() or 4)
+        assert same_bits(r["depth"][0], g[f"depth_{y}"]) and same_bits(r["color"][0], g[f"color_{y}"])
+        assert same_bits(r["normal"][0], g[f"normal_{y}"]) and r["ray_count"] == int(g[f"rays_{y}"])
+
+
+def test_oracle_matches_mirror_depth8_full_fixture(ca):
+    """C3 as BASELINE.json words it: mirror.json@1920x1080, bounces 8 (identical to bounces 5: SURVEY fact 9)."""
+    g8 = np.load(os.path.join(GOLD, "full_mirror_1920x1080_b8.npz"))
+    g5 = np.load(os.path.join(GOLD, "full_mirror_1920x1080_b5.npz"))
+    assert int(g8["ray_count"]) == int(g5["ray_count"]) == 8712144
+    assert np.array_equal(g8["sum_color"], g5["sum_color"]) and float(g8["sum_depth"]) == float(g5["sum_depth"])
+    s = load_scene(ca, "mirror")
+    rows = (0, 1080, 8, 5, 9)    # every 9th 8-row block: 120 rows, checked against the samples that fall into them
+    r = oracle.oracle_render(s, bounces=8, rows=rows, threads=os.cpu_count() or 4)
+    ys = [y for y in range(1080) if (y // 8) % 9 == 5]
+    pos = {y: k for k, y in enumerate(ys)}
+    idx = g8["sample_idx"]
+    hit = 0
+    for j, i in enumerate(idx):
+        y, x = divmod(int(i), 1920)
+        if y in pos:
+            k = pos[y]
+            assert r["depth"][k, x].view(np.uint32) == g8["depth"][j].view(np.uint32)
+            assert same_bits(r["color"][k, x], g8["color"][j]) and same_bits(r["normal"][k, x], g8["normal"][j])
+            hit += 1
+    assert hit > 300
