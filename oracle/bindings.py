@@ -49,6 +49,30 @@ def ref_lib():
     return _ref
 
 
+_ref_cuda = None
+
+
+def ref_cudaminmax_lib():
+    """DIAGNOSTIC flavour of the reference build: unqualified min/max behave like nvcc's device float overloads
+    (fminf/fmaxf: a NaN operand is dropped).  None when not built.  Never the parity target."""
+    global _ref_cuda
+    if _ref_cuda is None:
+        path = os.path.join(HERE, "_ref", "libcutrace_ref_cudaminmax.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        _render_sig(L.ref_render)
+        _ref_cuda = L
+    return _ref_cuda
+
+
+def ref_cudaminmax_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
+    L = ref_cudaminmax_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libcutrace_ref_cudaminmax.so not built (needs /root/reference)")
+    return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)
+
+
 def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids):
     w, h = scene.size
     r = make_rows(h, rows)

@@ -13,7 +13,7 @@
  * rounded once, as in the reference headers compiled for the host with the
  * same flags (oracle/_ref, see oracle/Makefile).  Pinning: this restatement is
  * checked bit-for-bit against oracle/_ref (the reference's own headers
- * compiled in place) by tests/test_oracle_vs_ref.py and against the committed
+ * compiled in place) by tests/test_oracle_golden.py and against the committed
  * golden buffers under tests/golden/ that were generated from oracle/_ref.
  *
  * min/max semantics: the reference calls unqualified min()/max(); in the

@@ -34,10 +34,19 @@
 using std::asin;
 using std::atan2;
 using std::isfinite;
-using std::max;
-using std::min;
 using std::pow;
 using std::sqrt;
+#ifdef CTR_REF_CUDA_MINMAX
+// DIAGNOSTIC flavour (oracle/_ref/libcutrace_ref_cudaminmax.so): nvcc binds the unqualified min/max of device code
+// (default_schema.hpp:109-110,241; shading.hpp:87,91) to its float overloads, which behave like fminf/fmaxf
+// (a NaN operand is dropped), not like std::min/std::max (a < b selects).  Only used to COUNT how many pixels
+// that difference touches (tests/test_oracle_golden.py::test_cuda_minmax_semantics_gap); never the parity target.
+inline float min(float a, float b) { return fminf(a, b); }
+inline float max(float a, float b) { return fmaxf(a, b); }
+#else
+using std::max;
+using std::min;
+#endif
 
 #include "vector.hpp"
 #include "gpu_array.hpp"

@@ -2,6 +2,7 @@
 bunny), C3-deep (mirror with reflective walls, depth 8), C4 (4x4 bunny grid, 16 meshes), and the
 `cutrace` CLI end to end.  Reduced resolutions keep the oracle within seconds; full-size runs are
 checked through size-independent properties (BVH on/off bitwise equality, row-tiling reassembly)."""
+import ctypes as C
 import os
 import subprocess
 
@@ -130,6 +131,16 @@ def test_cli_drop_in(ca, tmp_path):
         assert im.size == (160, 90)
     frame = np.asarray(Image.open(tmp_path / "frame.jpg").convert("RGB")).astype(np.int32)
     assert np.abs(frame - q.astype(np.int32)).mean() < 4.0  # JPEG q=90 loss only
+    # the other two writers (images.hpp:26-66): decoded planes against the ORACLE's buffers quantised by the oracle's
+    # restatement (itself pinned to the reference text by tests/test_loader.py's hand-derived known answers)
+    fin = np.isfinite(o["depth"])
+    max_d = float(o["depth"][fin].max()) if fin.any() else 0.0    # kernel.hpp:120-125
+    oracle.oracle_lib().orc_quantise_depth(o["depth"].ctypes.data, 160 * 90, C.c_float(max_d), q.ctypes.data)
+    dm = np.asarray(Image.open(tmp_path / "depth_map.jpg").convert("RGB")).astype(np.int32)
+    assert np.abs(dm - q.astype(np.int32)).mean() < 4.0 and np.abs(dm[..., 0] - dm[..., 1]).max() <= 8
+    oracle.oracle_lib().orc_quantise_normal(o["normal"].ctypes.data, 160 * 90, q.ctypes.data)
+    nm = np.asarray(Image.open(tmp_path / "normal_map.jpg").convert("RGB")).astype(np.int32)
+    assert np.abs(nm - q.astype(np.int32)).mean() < 4.0
     # usage / failure exit codes (main.cu:9-12, 16-19): -1 and -2 (mod 256)
     assert subprocess.run([exe], capture_output=True).returncode == 255
     p = subprocess.run([exe, "scene/bunny_small.json"], cwd=tmp_path, capture_output=True, text=True)

@@ -135,6 +135,41 @@ def test_quantisation_matches_oracle(ca):
     assert out.tolist() == [[127, 255, 0]]
 
 
+def test_quantisers_known_answers_from_the_reference_text(ca):
+    """Known answers worked out BY HAND from the reference's formulas (not from any restatement of ours):
+      depth   inc/images.hpp:27-29   isfinite(v) ? (byte)(255 * (m - v) / m) : 0
+      normal  inc/images.hpp:48-54   norm <= 1e-6 ? (0,0,0) : (byte)(255 * (0.5 + 0.5 * normalized))
+      colour  inc/images.hpp:73-76   (byte)(255 * min(1, max(0, c)))        (byte casts truncate)
+    and the same vectors through the oracle's restatement, which pins it to the reference text as well."""
+    H, O = _lib.host_lib(), oracle.oracle_lib()
+    m = np.float32(8.0)
+    depth = np.array([8.0, 0.0, 4.0, 2.0, 6.0, np.inf, -np.inf, np.nan, 7.0], np.float32)
+    #  v = m -> 255*0/8 = 0;  v = 0 -> 255;  4 -> 127.5 -> 127;  2 -> 191.25 -> 191;  6 -> 63.75 -> 63;
+    #  non-finite -> 0;  7 -> 31.875 -> 31
+    want_d = [0, 255, 127, 191, 63, 0, 0, 0, 31]
+    normal = np.array([[0, 0, 1], [0, 0, -1], [0, 2, 0], [-1, 0, 0], [1e-7, 0, 0], [0, 0, 0], [1e-5, 0, 0], [0, -0.25, 0]],
+                      np.float32)
+    #  (0,0,1) -> 0.5+0.5*(0,0,1) = (.5,.5,1) -> (127,127,255);  (0,0,-1) -> (127,127,0);  (0,2,0) -> (127,255,127);
+    #  (-1,0,0) -> (0,127,127);  |n| = 1e-7 <= 1e-6 -> 0;  zero -> 0;  |n| = 1e-5 > 1e-6 -> (1,0,0) -> (255,127,127);
+    #  (0,-.25,0) -> (0,-1,0) -> (127,0,127)
+    want_n = [[127, 127, 255], [127, 127, 0], [127, 255, 127], [0, 127, 127], [0, 0, 0], [0, 0, 0], [255, 127, 127],
+              [127, 0, 127]]
+    color = np.array([[0.999, 1.3, -0.2], [0.5, 1.0, 0.0], [0.25, 0.75, 2.0], [np.nan, 0.004, 0.00392]], np.float32)
+    #  .999 -> 254.745 -> 254;  1.3 -> 1 -> 255;  -.2 -> 0;  .5 -> 127.5 -> 127;  .25 -> 63.75 -> 63;  .75 -> 191.25 -> 191;
+    #  NaN: max(0, NaN) = 0 (a < b is false) -> 0;  .004 -> 1.02 -> 1;  .00392 -> 0.9996 -> 0
+    want_c = [[254, 255, 0], [127, 255, 0], [63, 191, 255], [0, 1, 0]]
+    for L, pre in ((H, "ctr"), (O, "orc")):
+        out = np.zeros((len(depth), 3), np.uint8)
+        getattr(L, pre + "_quantise_depth")(depth.ctypes.data, len(depth), C.c_float(float(m)), out.ctypes.data)
+        assert out[:, 0].tolist() == want_d and np.array_equal(out[:, 0], out[:, 1]) and np.array_equal(out[:, 0], out[:, 2]), pre
+        out = np.zeros((len(normal), 3), np.uint8)
+        getattr(L, pre + "_quantise_normal")(normal.ctypes.data, len(normal), out.ctypes.data)
+        assert out.tolist() == want_n, pre
+        out = np.zeros((len(color), 3), np.uint8)
+        getattr(L, pre + "_quantise_color")(color.ctypes.data, len(color), out.ctypes.data)
+        assert out.tolist() == want_c, pre
+
+
 def test_jpeg_writer_produces_a_decodable_image(ca, tmp_path):
     from PIL import Image
     w, h = 67, 45  # not multiples of 8
