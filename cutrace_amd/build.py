@@ -31,6 +31,11 @@ HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I" +
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC",
     "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics",
+    # no SLP vectorisation: left to itself the compiler pairs scalar f32 multiplies/adds into v_pk_* and pays for it with
+    # v_mov / v_pk_mov shuffles to assemble the register pairs — a packed op issues at half rate (scripts/valu_issue.hip),
+    # so that is a loss; the packed instructions that DO pay (SGPR-pair operands) are written out by hand.
+    # Measured on one box: bunny 1.38 -> 1.24 ms, 64k-triangle bunny 3.18 -> 2.76 ms.
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function", "-I" + INC, "-I" + CSRC,
 ]
 

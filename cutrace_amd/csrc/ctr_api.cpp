@@ -70,8 +70,8 @@ DCam to_dcam(const ctr_camera &c) {
 
 void make_tri(const ctr_vec3 &p1, const ctr_vec3 &p2, const ctr_vec3 &p3, uint32_t orig, DTri &T, float *gn) {
   f3 a = sub(p2, p1), b = sub(p2, p3);  // default_schema.hpp:58
-  T.ax = a.x; T.ay = a.y; T.az = a.z;
-  T.bx = b.x; T.by = b.y; T.bz = b.z;
+  T.ab[0][0] = a.x; T.ab[1][0] = a.y; T.ab[2][0] = a.z;
+  T.ab[0][1] = b.x; T.ab[1][1] = b.y; T.ab[2][1] = b.z;
   T.px = p2.x; T.py = p2.y; T.pz = p2.z;
   f3 n = cross(a, b);
   T.nx = n.x; T.ny = n.y; T.nz = n.z;
@@ -349,10 +349,23 @@ int refresh_linear_meshes(ctr_scene *s) {
         HIP_TRY(hipMemcpy(s->d_tris + slot0, &s->h_tris[slot0], risky.size() * sizeof(DTri), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s->d_gnorm + 4 * (size_t)slot0, &s->h_gn[4 * (size_t)slot0], risky.size() * 4 * sizeof(float), hipMemcpyHostToDevice));
       }
-      // leaf descriptor of the guard records (relative to the mesh's first triangle), 0 = none
-      const uint32_t desc = risky.empty() ? 0u : (BVH_LEAF_FLAG | ((uint32_t)risky.size() << 24) | g.tri_count);
-      s->h_meshes[g.mesh_pos].bvh_root = desc;
-      s->h_objs[g.obj_index].bvh_root = desc;
+      // the walk starts at node `bvh_root`: the root (0), or — with guard records — the mesh's extra node, whose
+      // children are the guard leaf (relative to the mesh's first triangle) and the root, both with unbounded boxes
+      const uint32_t start = risky.empty() ? 0u : g.node_count;
+      if (!risky.empty()) {
+        DNode4 gn4;
+        memset(&gn4, 0, sizeof(gn4));
+        for (int c = 0; c < 4; c++) {
+          const bool used = c < 2;
+          for (int a = 0; a < 3; a++) { gn4.lo[a][c] = used ? -3.0e38f : 3.4028235e38f; gn4.hi[a][c] = used ? 3.0e38f : 3.4028235e38f; }
+          gn4.child[c] = BVH_LEAF_FLAG;
+        }
+        gn4.child[0] = BVH_LEAF_FLAG | ((uint32_t)risky.size() << 24) | g.tri_count;
+        gn4.child[1] = 0u;  // the root
+        HIP_TRY(hipMemcpy(s->d_nodes4 + g.node_begin + g.node_count, &gn4, sizeof(DNode4), hipMemcpyHostToDevice));
+      }
+      s->h_meshes[g.mesh_pos].bvh_root = start;
+      s->h_objs[g.obj_index].bvh_root = start;
       HIP_TRY(hipMemcpy(s->d_meshes + g.mesh_pos, &s->h_meshes[g.mesh_pos], sizeof(DObj), hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy(s->d_objs + g.obj_index, &s->h_objs[g.obj_index], sizeof(DObj), hipMemcpyHostToDevice));
       g.guarded = risky;
@@ -483,6 +496,8 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         O.node_count = (uint32_t)mnodes.size();
         O.bvh_root = 0;  // node 0 of the mesh; child descriptors stay relative to the mesh's first node / first triangle
         nodes4.insert(nodes4.end(), mnodes.begin(), mnodes.end());
+        nodes4.emplace_back();  // the mesh's spare node (guard records, refresh_linear_meshes); unused = all zero
+        memset(&nodes4.back(), 0, sizeof(DNode4));
         {
           ctr_scene::MeshGuard g;
           g.node_begin = O.node_begin;

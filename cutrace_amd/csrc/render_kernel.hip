@@ -87,6 +87,12 @@ struct V3 { float x, y, z; };
 typedef float float2_ __attribute__((ext_vector_type(2)));
 // d = s * v.{lo|hi} - k.{lo|hi} for both halves of the SGPR pair s: v_pk_fma_f32 with op_sel choosing
 // which half of the VGPR pairs v and k is broadcast (vsel/ksel: 0 = low, 1 = high), k negated
+// d = s * v.{lo|hi} (both halves of the SGPR pair s times ONE broadcast half of the VGPR pair v)
+#define PKMULB(d, s, v, vsel)                                                                                   \
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0," #vsel "] op_sel_hi:[1," #vsel "]" : "=v"(d) : "s"(s), "v"(v))
+// d = s * v.{lo|hi} + acc (acc: a full pair)
+#define PKFMAB(d, s, v, vsel, acc)                                                                              \
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #vsel ",0] op_sel_hi:[1," #vsel ",1]" : "=v"(d) : "s"(s), "v"(v), "v"(acc))
 #define PKFMA(d, s, v, vsel, k, ksel)                                                                          \
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #vsel "," #ksel "] op_sel_hi:[1," #vsel "," #ksel "] "          \
       "neg_lo:[0,0,1] neg_hi:[0,0,1]"                                                                          \
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       } else {
         // ---- stand-alone triangle, default_schema.hpp:57-78 ----
         const CADDR DTri &T = A.tris[O.tri_begin];
-        const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
+        const V3 a = mk(T.ab[0][0], T.ab[1][0], T.ab[2][0]), b = mk(T.ab[0][1], T.ab[1][1], T.ab[2][1]);
         const V3 d = mk(T.px - ro.x, T.py - ro.y, T.pz - ro.z);
         const float alpha = det3(a, b, rd);
         const float beta = det3(d, b, rd) / alpha;
@@ -633,11 +639,17 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           // nearest hit so far (other objects, then this mesh)
           float lim = anyhit_now ? light_dist : best;
 
+          const float2_ ro_xy = {ro.x, ro.y};
           // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
           auto tri_test = [&](const auto &T, uint32_t tri_index, mask_t lanes_m) {
             mask_t c_m = lanes_m;
             if (STATS) { st[2]++; st[7] += __builtin_popcountll(lanes_m); }
-            const float dx = T.px - ro.x, dy = T.py - ro.y, dz = T.pz - ro.z;
+            // d = p2 - start (default_schema.hpp:58): x and y in one packed subtraction (same IEEE result)
+            const float2_ dxy = ldpair2(&T.px) - ro_xy;
+            const float dx = dxy.x, dy = dxy.y, dz = T.pz - ro.z;
+            uint32_t sgn = 0;
+            float sA1 = 0.f, sA2 = 0.f, absa = 0.f, dmax = 0.f, E = 0.f;
+            mask_t flat_m = 0ull;
             if (PREFILTER) {
               // Conservative reject test.  Same quantities as the exact test
               // (alpha = det[a b c], A1 = det[d b c], A2 = det[a d c]) evaluated with FMAs
@@ -645,22 +657,40 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               // evaluation's and the reference's rounding, and a
               // NaN anywhere makes the lane a candidate.
               const float alpha = __builtin_fmaf(rd.x, T.nx, __builtin_fmaf(rd.y, T.ny, rd.z * T.nz));
-              const float qx = __builtin_fmaf(dy, rd.z, -(dz * rd.y));
-              const float qy = __builtin_fmaf(dz, rd.x, -(dx * rd.z));
-              const float qz = __builtin_fmaf(dx, rd.y, -(dy * rd.x));
-              const float A1n = __builtin_fmaf(T.bx, qx, __builtin_fmaf(T.by, qy, T.bz * qz));  // = -A1
-              const float A2 = __builtin_fmaf(T.ax, qx, __builtin_fmaf(T.ay, qy, T.az * qz));
-              const uint32_t sgn = __float_as_uint(alpha) & 0x80000000u;
-              const float sA1 = __uint_as_float(__float_as_uint(A1n) ^ sgn ^ 0x80000000u);
-              const float sA2 = __uint_as_float(__float_as_uint(A2) ^ sgn);
-              const float absa = fabsf(alpha);
-              const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+              float2_ q_xy, q_z;
+              q_xy.x = __builtin_fmaf(dy, rd.z, -(dz * rd.y));
+              q_xy.y = __builtin_fmaf(dz, rd.x, -(dx * rd.z));
+              q_z.x = __builtin_fmaf(dx, rd.y, -(dy * rd.x));
+              q_z.y = 0.0f;
+              // (a.q, b.q) = (A2, -A1) together: the (a, b) pairs of the record times q, three packed instructions
+              float2_ m;
+              PKMULB(m, ldpair(T.ab[0]), q_xy, 0);
+              PKFMAB(m, ldpair(T.ab[1]), q_xy, 1, m);
+              PKFMAB(m, ldpair(T.ab[2]), q_z, 0, m);
+              // (s A2, s A1) with s = sign(alpha): multiply by (s, -s), exact
+              sgn = __float_as_uint(alpha) & 0x80000000u;
+              float2_ s1;
+              s1.x = __uint_as_float(sgn | 0x3f800000u);
+              s1.y = 0.0f;
+              float2_ sm;
+              asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(sm) : "v"(m), "v"(s1));
+              sA2 = sm.x;
+              sA1 = sm.y;
+              absa = fabsf(alpha);
+              dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
               // kappa * max(dmax,emax) * emax * cmax; both operands are >= 0, so the maximum is taken on the
               // bit patterns (fmaxf would first canonicalise the loaded ke2: one more VALU op per triangle)
               const uint32_t e_a = __float_as_uint(dmax * T.ke), e_b = __float_as_uint(T.ke2);
-              const float E = __uint_as_float(e_a > e_b ? e_a : e_b) * cmax;
-              const mask_t rej = FCMP(sA1, -E, FC_OLT) | FCMP(sA2, -E, FC_OLT) | FCMP(sA1 + sA2, absa + E, FC_OGT);
-              const mask_t flat_m = FCMP(absa, E, FC_OLE);  // alpha within rounding of 0: always a candidate
+              E = __uint_as_float(e_a > e_b ? e_a : e_b) * cmax;
+              // reject if  s A1 < -E  or  s A2 < -E  or  s A1 + s A2 > |alpha| + E:  ONE comparison of the smallest
+              // of the three slacks (v_min3 drops a NaN operand: a lane is rejected only on a definite violation)
+              float slack;
+              {
+                const float third = absa - (sA1 + sA2);
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(slack) : "v"(sA1), "v"(sA2), "v"(third));
+              }
+              const mask_t rej = FCMP(slack, -E, FC_OLT);
+              flat_m = FCMP(absa, E, FC_OLE);  // alpha within rounding of 0: always a candidate
               c_m = lanes_m & (~rej | flat_m);
               if (c_m == 0ull) return;
               if (t_filter) {
@@ -702,7 +732,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             if (INVB(c_m)) {
               // ---- triangle::intersect, default_schema.hpp:57-78: the four determinants in the
               //      reference's operation order ----
-              const V3 a = mk(T.ax, T.ay, T.az), b = mk(T.bx, T.by, T.bz);
+              const V3 a = mk(T.ab[0][0], T.ab[1][0], T.ab[2][0]), b = mk(T.ab[0][1], T.ab[1][1], T.ab[2][1]);
               const V3 d = mk(dx, dy, dz);
               const float alpha = det3(a, b, rd);
               const float A1 = det3(d, b, rd), A2 = det3(a, d, rd), A0 = det3(a, b, d);
@@ -823,8 +853,10 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               stack_v = ctr_writelane(__builtin_amdgcn_readfirstlane(d), __builtin_amdgcn_readfirstlane(sp), stack_v);
               sp++;
             };
-            uint32_t cur = 0;  // node 0 is the root (a mesh that fits one leaf has a root with one child)
-            const uint32_t guard_desc = O.bvh_root;
+            // node 0 is the root (a mesh that fits one leaf has a root with one child).  A mesh with guard
+            // records (triangles every lane must meet whatever their box, ctr_api.cpp refresh_linear_meshes)
+            // starts one node earlier, at an extra node whose children are the guard leaf and the root.
+            uint32_t cur = O.bvh_root;
 #ifdef CTR_TIMING
             t_w0 = __builtin_readcyclecounter();
             tm[4] += t_w0 - t_bb;
@@ -837,41 +869,34 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
               box_hits2(N, 2, h2, h3);
               if (STATS) st[6] += __builtin_popcountll(h0 | h1 | h2 | h3);
               const uint32_t d0 = N.child[0], d1 = N.child[1], d2 = N.child[2], d3 = N.child[3];
-              const bool rev = ((neg_bits >> N.axis) & 1u) != 0u;  // wave-uniform: far end of the order axis first
-              // which children are hit leaves / hit inner nodes, as 4-bit scalars
-              const uint32_t hit_bits = (h0 != 0ull ? 1u : 0u) | (h1 != 0ull ? 2u : 0u) | (h2 != 0ull ? 4u : 0u) | (h3 != 0ull ? 8u : 0u);
-              const uint32_t leaf_bits = ((d0 >> 31) | ((d1 >> 31) << 1) | ((d2 >> 31) << 2) | ((d3 >> 31) << 3));
-              // ---- hit leaves, nearest first: ONE copy of the triangle code, the child picked by scalar selects ----
-              uint32_t todo = hit_bits & leaf_bits;
-              // (pseudo-child 4, at the root only: the mesh's guard records — triangles whose plane contains an
-              //  eye or a light, which must meet every lane whatever their box; almost always none)
-              if (cur == 0u && guard_desc != 0u) todo |= 16u;
-              while (todo != 0u) {
-                const uint32_t c = rev ? 31u - (uint32_t)__builtin_clz(todo) : (uint32_t)__builtin_ctz(todo);
-                todo &= ~(1u << c);
-                const uint32_t d = c == 0u ? d0 : c == 1u ? d1 : c == 2u ? d2 : c == 3u ? d3 : guard_desc;
-                const mask_t h = c == 0u ? h0 : c == 1u ? h1 : c == 2u ? h2 : c == 3u ? h3 : bb_m;
-                leaf(d, h);
-                if (ANYHIT) {
-                  if (bb_m == 0ull) break;
-                }
-              }
-              if (ANYHIT) {
-                if (bb_m == 0ull) break;
-              }
-              // ---- hit inner children: the nearest is visited next, the others wait on the stack, farthest pushed first ----
-              const uint32_t inner = hit_bits & ~leaf_bits;
+              // children are stored sorted along the node's order axis; a wave whose lead ray points the other
+              // way takes them in reverse (wave-uniform selects): e0/g0 = nearest ... e3/g3 = farthest
+              const bool rev = ((neg_bits >> N.axis) & 1u) != 0u;
+              const uint32_t e0 = rev ? d3 : d0, e1 = rev ? d2 : d1, e2 = rev ? d1 : d2, e3 = rev ? d0 : d3;
+              const mask_t g0 = rev ? h3 : h0, g1 = rev ? h2 : h1, g2 = rev ? h1 : h2, g3 = rev ? h0 : h3;
+              // ONE pass, farthest child first: a hit leaf is tested at once; a hit inner child becomes the node to
+              // visit next and whatever was to be visited next is pushed — so the nearest inner child is visited
+              // next and the stack pops nearest-first.  No per-child bookkeeping beyond two scalar tests.
               uint32_t next = 0xFFFFFFFFu;
-              if (inner != 0u) {
-                auto take = [&](uint32_t bit, uint32_t d) {
-                  if (inner & bit) {
-                    if (next != 0xFFFFFFFFu) push(next);
-                    next = d;
-                  }
-                };
-                if (rev) { take(1u, d0); take(2u, d1); take(4u, d2); take(8u, d3); }
-                else     { take(8u, d3); take(4u, d2); take(2u, d1); take(1u, d0); }
-              }
+              bool done = false;
+#define CTR_CHILD(e, g)                                             \
+  if (!done && (g) != 0ull) {                                       \
+    if ((e) & BVH_LEAF_FLAG) {                                      \
+      leaf((e), (g));                                               \
+      if (ANYHIT) {                                                 \
+        if (bb_m == 0ull) done = true;                              \
+      }                                                             \
+    } else {                                                        \
+      if (next != 0xFFFFFFFFu) push(next);                          \
+      next = (e);                                                   \
+    }                                                               \
+  }
+              CTR_CHILD(e3, g3)
+              CTR_CHILD(e2, g2)
+              CTR_CHILD(e1, g1)
+              CTR_CHILD(e0, g0)
+#undef CTR_CHILD
+              if (done) break;
               if (next == 0xFFFFFFFFu) {
                 if (sp == 0) break;
                 sp--;

@@ -28,13 +28,13 @@
 #include <stdint.h>
 
 struct DTri {
-  float ax, ay, az;     // a = p2 - p1
-  float bx, by, bz;     // b = p2 - p3
-  float px, py, pz;     // p2
+  float ab[3][2];       // ab[axis][0] = a = p2 - p1, ab[axis][1] = b = p2 - p3: (a, b) of one axis is an aligned SGPR
+                        // pair, so that one v_pk_fma_f32 advances a.q and b.q together (prefilter)
+  float px, py, pz;     // p2; (px, py) is an aligned pair as well
+  uint32_t orig;        // index of this triangle in the ORIGINAL (file-order) array: tie-break key
   float nx, ny, nz;     // a x b (prefilter only)
   float ke;             // kappa * emax,   emax = max|component of a,b| (prefilter error scale)
   float ke2;            // kappa * emax^2
-  uint32_t orig;        // index of this triangle in the ORIGINAL (file-order) array: tie-break key
   float pad1;
 };
 static_assert(sizeof(DTri) == 64, "DTri must be one 64-byte line");
@@ -46,8 +46,9 @@ struct DObj {
   uint32_t tri_count;   // mesh: number of triangles; triangle: 1
   uint32_t node_begin;  // mesh: first DNode4 of its BVH (= its root)
   uint32_t node_count;  // mesh: number of BVH nodes
-  uint32_t bvh_root;    // mesh: leaf descriptor of its GUARD records (triangles every lane that enters the mesh must
-                        // meet, whatever their box; ctr_api.cpp refresh_linear_meshes), 0 = none.  The root is node 0.
+  uint32_t bvh_root;    // mesh: node the walk starts at: 0 = the root, or node_count = the mesh's spare node, which leads
+                        // to its GUARD records (triangles every lane that enters the mesh must meet, whatever their
+                        // box; ctr_api.cpp refresh_linear_meshes) and then to the root
   uint32_t index;       // position in the scene's object list (hit_id; ties on t go to the lower index)
   // triangle: unused
   // mesh    : f[0..2] bbox.min, f[3..5] bbox.max

@@ -5,7 +5,7 @@ set -e
 OUT=${1:-profiles/r02/valu_mix.json}
 TMP=$(mktemp -d)
 hipcc --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
-  -munsafe-fp-atomics -Iinclude -Icutrace_amd/csrc -S --cuda-device-only -o $TMP/rk.s cutrace_amd/csrc/render_kernel.hip 2>/dev/null
+  -munsafe-fp-atomics -fno-slp-vectorize -Iinclude -Icutrace_amd/csrc -S --cuda-device-only -o $TMP/rk.s cutrace_amd/csrc/render_kernel.hip 2>/dev/null
 python3 scripts/valu_mix.py $TMP/rk.s render_kernelILj43E > $OUT
 rm -rf $TMP
 cat $OUT
