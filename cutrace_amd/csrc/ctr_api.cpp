@@ -114,6 +114,7 @@ struct ctr_scene {
   bool has_mesh = false;
   bool all_opaque = true;
   bool need_cold = false;
+  bool any_bounce = false;    // some material reflects or transmits (>= 1e-6): the recursion can go below depth 0
   size_t mesh_bytes = 0;      // triangles + BVH nodes
   DCam cam{};                 // camera 0 (image size of every camera)
   DCam *d_cams = nullptr;     // device camera array (>= 1 entry)
@@ -231,6 +232,7 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.n_mat = s->n_mat;
   L.has_mesh = s->has_mesh ? 1u : 0u;
   L.need_cold_frames = s->need_cold ? 1u : 0u;
+  L.any_bounce = s->any_bounce ? 1u : 0u;
   L.cams = s->d_cams;
   L.shards = s->d_shards;
   L.w = s->cam.w;
@@ -595,12 +597,13 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     lights[i] = DLight{l.type, l.v.x, l.v.y, l.v.z, l.color.x, l.color.y, l.color.z, 0.f};
   }
   std::vector<DMat> mats(d->n_materials);
-  bool all_opaque = true, need_cold = false;
+  bool all_opaque = true, need_cold = false, any_bounce = false;
   for (uint64_t i = 0; i < d->n_materials; i++) {
     const ctr_material &m = d->materials[i];
     mats[i] = DMat{m.color.x, m.color.y, m.color.z, m.specular, m.reflexivity, m.phong_exp, m.transparency, 0.f};
     if (!(m.transparency == 0.0f)) all_opaque = false;
     if ((double)m.transparency >= 1e-6 && (double)m.reflexivity >= 1e-6) need_cold = true;
+    if ((double)m.transparency >= 1e-6 || (double)m.reflexivity >= 1e-6) any_bounce = true;
   }
 
   auto *s = new ctr_scene();
@@ -613,6 +616,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->mesh_bytes = tris.size() * sizeof(DTri) + nodes.size() * sizeof(DNode) + nodes4.size() * sizeof(DNode4);
   s->all_opaque = all_opaque;
   s->need_cold = need_cold;
+  s->any_bounce = any_bounce;
   DCam cam = to_dcam(d->cam);
   s->cam = cam;
 

@@ -161,14 +161,15 @@ __device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a
 __device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }
 
 // A suspended ray_color activation (shading.hpp:116-154) lives in LDS, never in scratch:
-//   hot  fields 0..5 : rgb so far (3), reflective, translucent, stage (1 = waiting for the
-//                      reflection child, 2 = for the pass-through child)
-//   cold fields 6..11: incoming->start + distance*incoming->dir (3), incoming->dir (3); only
-//                      materials that BOTH reflect and transmit need them (A.nf == 12)
+//   hot  fields 0..3 : rgb so far (3), material index | stage << 30 (stage 1 = waiting for the
+//                      reflection child, 2 = for the pass-through child; the material record says
+//                      how reflective / translucent the surface is)
+//   cold fields 4..9 : incoming->start + distance*incoming->dir (3), incoming->dir (3); only
+//                      materials that BOTH reflect and transmit need them (A.nf == 10)
 // Layout [wave][frame][field][lane]: lane-contiguous dwords, so a push/pop is conflict-free
 // whatever each lane's own stack depth is.  bounces_left of a frame is implied by its depth
 // (every push decrements it): bl = bounces - depth.
-enum { F_R = 0, F_G, F_B, F_REFL, F_TRANSL, F_STAGE, F_PX, F_PY, F_PZ, F_DX, F_DY, F_DZ };
+enum { F_R = 0, F_G, F_B, F_MAT, F_PX, F_PY, F_PZ, F_DX, F_DY, F_DZ };  // F_MAT: material index | stage << 30
 
 struct KArgs {
   const CADDR DObj *objs;      // every object in scene order (hit records)
@@ -193,8 +194,9 @@ struct KArgs {
   float fudge;
   int bounces;
   uint32_t has_mesh;
-  uint32_t nf;        // LDS dwords per stack frame: 6, or 12 when some material reflects AND transmits
-  uint32_t frames;    // LDS stack frames per lane (= max(bounces, 1))
+  uint32_t nf;        // LDS dwords per stack frame: 4, or 10 when some material reflects AND transmits
+  uint32_t frames;    // LDS stack frames per lane: the recursion depth that can be reached (bounces, or 1 when no
+                      // material reflects or transmits: ray_color then never recurses)
   const CADDR uint32_t *order;  // dispatch slot -> wave (tile) index, or null = identity
   uint32_t *cost;               // per wave (tile): shader-clock ticks it took, or null
 };
@@ -1071,8 +1073,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       const bool do_trans = more && (double)translucent >= 1e-6;
       if (do_refl || do_trans) {
         STK(sp, F_R) = fin.x; STK(sp, F_G) = fin.y; STK(sp, F_B) = fin.z;
-        STK(sp, F_REFL) = reflective; STK(sp, F_TRANSL) = translucent;
-        STK(sp, F_STAGE) = do_refl ? 1.0f : 2.0f;
+        STK(sp, F_MAT) = __uint_as_float(mat_i | (do_refl ? 1u << 30 : 2u << 30));  // the material says reflective / translucent
         if (do_refl && do_trans) {  // the pass-through child is cast after the reflection returns
           STK(sp, F_PX) = pos.x; STK(sp, F_PY) = pos.y; STK(sp, F_PZ) = pos.z;
           STK(sp, F_DX) = in_d.x; STK(sp, F_DY) = in_d.y; STK(sp, F_DZ) = in_d.z;
@@ -1104,12 +1105,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         }
         --sp;
         V3 rgb = mk(STK(sp, F_R), STK(sp, F_G), STK(sp, F_B));
-        const float f_transl = STK(sp, F_TRANSL);
-        if (STK(sp, F_STAGE) == 1.0f) {
-          rgb = vadd(rgb, vscale(out_rgb, STK(sp, F_REFL)));  // shading.hpp:138
+        const uint32_t f_mat = __float_as_uint(STK(sp, F_MAT));
+        const CADDR DMat &FM = A.mats[f_mat & 0x3FFFFFFFu];
+        const float f_transl = FM.transparency;
+        if ((f_mat >> 30) == 1u) {
+          rgb = vadd(rgb, vscale(out_rgb, FM.reflexivity));  // shading.hpp:138
           if ((double)f_transl >= 1e-6) {
             STK(sp, F_R) = rgb.x; STK(sp, F_G) = rgb.y; STK(sp, F_B) = rgb.z;
-            STK(sp, F_STAGE) = 2.0f;
+            STK(sp, F_MAT) = __uint_as_float((f_mat & 0x3FFFFFFFu) | (2u << 30));
             in_d = mk(STK(sp, F_DX), STK(sp, F_DY), STK(sp, F_DZ));
             ro = mk(STK(sp, F_PX), STK(sp, F_PY), STK(sp, F_PZ));
             rd = in_d;
@@ -1346,8 +1349,8 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.fudge = L.fudge;
   A.bounces = L.bounces;
   A.has_mesh = L.has_mesh;
-  A.nf = L.need_cold_frames ? 12u : 6u;
-  A.frames = (uint32_t)(L.bounces > 0 ? L.bounces : 1);
+  A.nf = L.need_cold_frames ? 10u : 4u;
+  A.frames = (uint32_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1);
   A.order = (const CADDR uint32_t *)L.order;
   A.cost = L.cost;
   size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);

@@ -131,6 +131,7 @@ struct RenderLaunch {
   uint32_t n_obj, n_light, n_mat;
   uint32_t has_mesh;
   uint32_t need_cold_frames;  // some material both reflects and transmits (>= 1e-6 each)
+  uint32_t any_bounce;        // some material reflects or transmits: only then does ray_color recurse at all
   const DCam *cams;           // device array, one camera per frame
   uint32_t w, h;
   uint32_t first_frame, n_frames;
