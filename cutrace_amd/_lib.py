@@ -76,7 +76,7 @@ HIP_SYMBOLS = [
     "ctr_abi_version", "ctr_last_error", "ctr_device_count", "ctr_scene_create", "ctr_scene_destroy",
     "ctr_scene_size", "ctr_scene_set_size", "ctr_render", "ctr_render_device", "ctr_set_variant",
     "ctr_scene_set_cameras", "ctr_render_device_batch",
-    "ctr_algorithmic_bytes", "ctr_frame_alloc", "ctr_frame_free", "ctr_tile_costs", "ctr_last_counters",
+    "ctr_algorithmic_bytes", "ctr_frame_alloc", "ctr_frame_free", "ctr_tile_costs", "ctr_last_counters", "ctr_selftest_exact_math",
     "ctr_multi_create", "ctr_multi_destroy", "ctr_multi_devices", "ctr_multi_transport", "ctr_multi_size", "ctr_multi_set_size",
     "ctr_multi_set_variant", "ctr_render_multi", "ctr_multi_kernel_ms", "ctr_reinterleave_device",
 ]
@@ -143,27 +143,31 @@ def hip_lib():
                                               C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ctr_algorithmic_bytes.argtypes = [C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64)]
-        if not hasattr(L, "ctr_frame_alloc"):  # an older build loaded through CUTRACE_AMD_LIB for A/B timing
-            _hip = L
-            return _hip
-        L.ctr_frame_alloc.argtypes = [C.c_uint64, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
-                                      C.POINTER(C.POINTER(C.c_float))]
-        L.ctr_frame_free.argtypes = [C.POINTER(C.c_float)]
-        L.ctr_frame_free.restype = None
-        L.ctr_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
-        L.ctr_multi_destroy.argtypes = [C.c_void_p]
-        L.ctr_multi_destroy.restype = None
-        L.ctr_multi_devices.argtypes = [C.c_void_p]
-        L.ctr_multi_transport.argtypes = [C.c_void_p]
-        L.ctr_multi_transport.restype = C.c_char_p
-        L.ctr_multi_set_size.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
-        L.ctr_multi_set_variant.argtypes = [C.c_void_p, C.c_uint32]
-        L.ctr_render_multi.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.POINTER(RenderStats)]
-        L.ctr_reinterleave_device.argtypes = [C.POINTER(ReintPart), C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.ctr_multi_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
-        L.ctr_last_counters.argtypes = [C.c_void_p, C.c_void_p]
-        L.ctr_tile_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        # entry points added after round 1 (an older build may be loaded through CUTRACE_AMD_LIB for A/B timing)
+        opt = {
+            "ctr_frame_alloc": ([C.c_uint64, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
+                                 C.POINTER(C.POINTER(C.c_float))], C.c_int),
+            "ctr_frame_free": ([C.POINTER(C.c_float)], None),
+            "ctr_multi_create": ([C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+            "ctr_multi_destroy": ([C.c_void_p], None),
+            "ctr_multi_devices": ([C.c_void_p], C.c_int),
+            "ctr_multi_transport": ([C.c_void_p], C.c_char_p),
+            "ctr_multi_size": ([C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], C.c_int),
+            "ctr_multi_set_size": ([C.c_void_p, C.c_uint64, C.c_uint64], C.c_int),
+            "ctr_multi_set_variant": ([C.c_void_p, C.c_uint32], C.c_int),
+            "ctr_render_multi": ([C.c_void_p, C.c_float, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(RenderStats)], C.c_int),
+            "ctr_reinterleave_device": ([C.POINTER(ReintPart), C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+            "ctr_multi_kernel_ms": ([C.c_void_p, C.POINTER(C.c_double), C.c_int], C.c_int),
+            "ctr_selftest_exact_math": ([C.POINTER(C.c_uint64)], C.c_int),
+            "ctr_last_counters": ([C.c_void_p, C.c_void_p], C.c_int),
+            "ctr_tile_costs": ([C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)], C.c_int),
+        }
+        for name, (argt, rest) in opt.items():
+            if hasattr(L, name):
+                fn = getattr(L, name)
+                fn.argtypes = argt
+                fn.restype = rest
         _hip = L
     return _hip

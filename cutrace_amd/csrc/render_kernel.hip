@@ -151,6 +151,42 @@ __device__ __forceinline__ V3 vcross(V3 a, V3 o) {
 }
 __device__ __forceinline__ float vnorm(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 __device__ __forceinline__ V3 vnormalized(V3 a) { return vscale(a, 1.0f / vnorm(a)); }
+// The same two IEEE results — n = sqrtf(x) and 1.0f / n, correctly rounded — for the whole wave at about half
+// the instructions when every active lane's x lies in [2^-80, 2^80].  hipcc's correctly rounded sqrtf / division
+// wrap the arithmetic below in denormal scaling (v_div_scale, a pre-multiply by 2^32) and special-case fix-ups
+// (v_div_fixup, v_cmp_class) that cannot trigger in that range; what remains is
+//   sqrt: s = v_sqrt_f32(x) (1 ulp), then the neighbour whose residual x - s'.s changes sign
+//   1/n:  y = v_rcp_f32(n), one Newton step, then two residual corrections q += (1 - n q) y
+// in the same operations and order, hence the same bits (checked exhaustively over all 2^24 mantissa / exponent-
+// parity patterns by ctr_selftest_exact_math, tests/test_gpu_parity.py).  Any lane outside the range (a zero
+// vector, inf, NaN): the whole wave takes the library path.
+__device__ __forceinline__ void norm_and_inverse(float x, float &n, float &inv) {
+  if (BALLOT(!(x >= 0x1p-80f && x <= 0x1p80f)) != 0ull) {
+    n = sqrtf(x);
+    inv = 1.0f / n;
+    return;
+  }
+  const float s0 = __builtin_amdgcn_sqrtf(x);
+  const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
+  const float rm = __builtin_fmaf(-sm, s0, x), rp = __builtin_fmaf(-sp, s0, x);
+  float s = (rm <= 0.0f) ? sm : s0;
+  s = (rp > 0.0f) ? sp : s;
+  n = s;
+  float y = __builtin_amdgcn_rcpf(s);
+  const float e = __builtin_fmaf(-s, y, 1.0f);
+  y = __builtin_fmaf(e, y, y);
+  float q = y;                                   // 1.0f * y
+  const float r0 = __builtin_fmaf(-s, q, 1.0f);
+  q = __builtin_fmaf(r0, y, q);
+  const float r1 = __builtin_fmaf(-s, q, 1.0f);
+  inv = __builtin_fmaf(r1, y, q);
+}
+// a.normalized() and a.norm() together (vector.hpp:77-92), through norm_and_inverse
+__device__ __forceinline__ V3 vnormalized_n(V3 a, float &n) {
+  float inv;
+  norm_and_inverse(a.x * a.x + a.y * a.y + a.z * a.z, n, inv);
+  return vscale(a, inv);
+}
 // matrix::determinant, vector.hpp:218-224 (columns c0,c1,c2)
 __device__ __forceinline__ float det3(V3 c0, V3 c1, V3 c2) {
   float a = c0.x, b = c1.x, c = c2.x, d = c0.y, e = c1.y, f = c2.y, g = c0.z, h = c1.z, i = c2.z;
@@ -954,7 +990,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         const CADDR DObj &H = A.objs[bobj];
         mat_i = H.mat;
         pos = vadd(ro, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
-        in_dn = vnormalized(in_d);
+        { float unused_n; in_dn = vnormalized_n(in_d, unused_n); }
         const uint32_t ht = H.type;
         if (ht == CTR_OBJ_SPHERE) {
           // default_schema.hpp:245-246: hit uses the NORMALIZED direction
@@ -985,7 +1021,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         // phong prologue, shading.hpp:66-76
         const CADDR DMat &M = A.mats[mat_i];
         fin = vscale(mk(M.cx, M.cy, M.cz), ambient);
-        nn = vnormalized(normal);
+        { float unused_n; nn = vnormalized_n(normal, unused_n); }
         li = 0;
         act = ACT_LIGHT;
       }
@@ -1051,11 +1087,11 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           distance = INFINITY;
         } else {                         // default_schema.hpp:305-308
           const V3 diff = vsub(mk(Lg.vx, Lg.vy, Lg.vz), ro);  // ro == *hit
-          direction = vnormalized(diff);
-          distance = vnorm(diff);
+          direction = vnormalized_n(diff, distance);
         }
-        rd = vnormalized(direction);  // shadow ray {*hit, direction.normalized()}, shading.hpp:80
-        light_dist = distance * vnorm(direction);
+        float dir_norm;
+        rd = vnormalized_n(direction, dir_norm);  // shadow ray {*hit, direction.normalized()}, shading.hpp:80
+        light_dist = distance * dir_norm;
         intensity = 0.0f;
         min_t = (float)(0.0 + 1e-3);  // last_hit = 0
         mode = M_SHADOW;
@@ -1386,6 +1422,42 @@ int launch_main(const RenderLaunch &L, hipStream_t s) {
 }
 
 }  // namespace
+
+// ---- self-test of norm_and_inverse against the library's correctly rounded sqrtf and division ----
+namespace {
+__global__ __launch_bounds__(256) void selftest_exact_math(unsigned long long *bad) {
+  // every mantissa (2^23) x both exponent parities, at exponents -79/-78, -1/0 and 78/79: thread t takes 6 values
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2^23-1
+  unsigned long long wrong = 0;
+  const int exps[6] = {127 - 79, 127 - 78, 126, 127, 127 + 78, 127 + 79};
+  for (int k = 0; k < 6; k++) {
+    float x = __uint_as_float(((uint32_t)exps[k] << 23) | m);
+    asm volatile("" : "+v"(x));
+    float n, inv;
+    norm_and_inverse(x, n, inv);
+    const float n_ref = sqrtf(x);
+    const float inv_ref = 1.0f / n_ref;
+    if (__float_as_uint(n) != __float_as_uint(n_ref) || __float_as_uint(inv) != __float_as_uint(inv_ref)) wrong++;
+  }
+  for (int off = 32; off > 0; off >>= 1) wrong += __shfl_xor(wrong, off);
+  if ((threadIdx.x & 63) == 0 && wrong) atomicAdd(bad, wrong);
+}
+}  // namespace
+
+extern "C" int ctr_selftest_exact_math(uint64_t *n_mismatch) {
+  if (!n_mismatch) return CTR_E_INVALID;
+  unsigned long long *d = nullptr;
+  hipError_t e = hipMalloc((void **)&d, sizeof(unsigned long long));
+  if (e != hipSuccess) return CTR_E_HIP_BASE + (int)e;
+  (void)hipMemset(d, 0, sizeof(unsigned long long));
+  hipLaunchKernelGGL(selftest_exact_math, dim3((1u << 23) / 256), dim3(256), 0, nullptr, d);
+  unsigned long long h = ~0ull;
+  e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return CTR_E_HIP_BASE + (int)e;
+  *n_mismatch = h;
+  return CTR_OK;
+}
 
 uint64_t ctr_launch_waves(const RenderLaunch &L) { return launch_waves(L); }
 

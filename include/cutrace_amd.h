@@ -248,6 +248,10 @@ int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
  * The first launch of a shape allocates the (small) cost/order buffers with hipMalloc: make that
  * launch before capturing ctr_render_device into a HIP graph, or capture under CTR_VAR_NO_REORDER. */
 int ctr_set_variant(ctr_scene *scene, uint32_t variant_bits);
+/* Self-test: the kernel's short-cut for n = sqrtf(x), 1.0f / n (both IEEE, correctly rounded; used where a vector
+ * is normalised) against the library versions, over every float mantissa and both exponent parities at the ends and
+ * the middle of the range the short-cut accepts.  n_mismatch must come back 0. */
+int ctr_selftest_exact_math(uint64_t *n_mismatch);
 /* Diagnostic: the 16 counter words of the last ctr_render on this handle.  [0] ray_count, [1] max-depth
  * bits; under CTR_VAR_STATS wave-level work: [4] casts (wave trips) [5] BVH nodes visited [6] triangle
  * prefilters [7] exact triangle tests [8] mesh entries [9] lanes active per cast (sum) [10] lanes whose ray

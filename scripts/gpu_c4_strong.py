@@ -6,11 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cutrace_amd import scenes
 gen = tempfile.mkdtemp()
-path = scenes.make_bunny_grid(gen, 4, 4)
+path = scenes.make_bunny_grid(gen)
 
 def run(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scene", path, "--width", "4096", "--height", "4096",
-           "--scaling", "strong", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--skip-probe"] + extra
+           "--scaling", "strong", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--skip-probe", "--no-extras"] + extra
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:

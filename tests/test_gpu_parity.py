@@ -464,3 +464,13 @@ def test_rays_coplanar_with_triangles(ca, tmp_path, seed):
     for k in ("depth", "normal", "color"):
         assert same_bits(fast[k], plain[k]), f"seed {seed}: {k}"
     assert fast["ray_count"] == plain["ray_count"] == o["ray_count"]
+
+
+def test_exact_sqrt_and_reciprocal_shortcut_is_exhaustively_correct(ca):
+    """The kernel normalises vectors with a shorter instruction sequence than hipcc's correctly rounded sqrtf and
+    division (render_kernel.hip norm_and_inverse); it must give the same bits for EVERY mantissa."""
+    import ctypes as C
+    from cutrace_amd import _lib
+    n = C.c_uint64(1)
+    assert _lib.hip_lib().ctr_selftest_exact_math(C.byref(n)) == 0
+    assert n.value == 0, f"{n.value} of {6 * 2**23} (sqrt, 1/sqrt) pairs differ from sqrtf / IEEE division"
