@@ -356,7 +356,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
   unsigned long long n_casts = (unsigned long long)__builtin_popcountll(BALLOT(in_image));
   unsigned long long n_aabb_tris = 0;
 
+  // Cold kernel arguments — what only the continuation needs (hit records, lights, materials) — are read from
+  // the kernarg segment where they are used instead of living in SGPRs across the object / BVH / triangle loops:
+  // the loops need every scalar register, and an argument kept through them is spilled to a VGPR lane and comes
+  // back by v_readlane (a half-rate VALU instruction per dword, every trip); an s_load from the scalar cache costs
+  // no VALU slot.  The pointer is made opaque once per trip so that the loads stay inside the trip.
+  const CADDR KArgs *AK = (const CADDR KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   while (BALLOT(mode != M_DONE) != 0ull) {
+    asm volatile("" : "+s"(AK));
     TSTAMP(t_trip0);
     const bool active = mode != M_DONE;
     const bool shadow_cast = mode == M_SHADOW;
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     V3 ria = mk(0, 0, 0);
     float ria_big = 0.f;
     float cmax = 0.f;
-    if (A.has_mesh) {
+    if (AK->has_mesh) {
       // 1-ulp reciprocals, clamped to +-1e30: an axis-parallel ray (d = 0 -> inf) then gives huge
       // FINITE slab distances with the right signs instead of inf - inf = NaN
       ria = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(rd.x), -1e30f), 1e30f),
@@ -447,10 +454,10 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         num = (dx * nx + dy * ny) + dz * nz;
         den = (rdx * nx + rdy * ny) + rdz * nz;
       };
-      const uint32_t n_pairs = (A.n_planes + 1u) >> 1;
+      const uint32_t n_pairs = (AK->n_planes + 1u) >> 1;
       for (uint32_t p = 0; p < n_pairs;) {
         if (n_pairs - p >= 3u) {
-          const CADDR DPlanePair &P0 = A.planes[p], &P1 = A.planes[p + 1], &P2 = A.planes[p + 2];
+          const CADDR DPlanePair &P0 = AK->planes[p], &P1 = AK->planes[p + 1], &P2 = AK->planes[p + 2];
           float2_ num0, den0, num1, den1, num2, den2;
           num_den(P0, num0, den0);
           num_den(P1, num1, den1);
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
             if (!plane_test(i21, num2.y, den2.y)) break;
           }
         } else {
-          const CADDR DPlanePair &P0 = A.planes[p];
+          const CADDR DPlanePair &P0 = AK->planes[p];
           float2_ num0, den0;
           num_den(P0, num0, den0);
           const uint32_t i00 = P0.index[0], i01 = P0.index[1];
@@ -488,11 +495,11 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     V3 sph_d = mk(0, 0, 0);
     float sph_dd = 0.f;
     bool sph_have = false;  // wave-uniform
-    for (uint32_t oi = 0; oi < A.n_oloop; ++oi) {
+    for (uint32_t oi = 0; oi < AK->n_oloop; ++oi) {
       if (ANYHIT) {
         if (BALLOT(live) == 0ull) break;
       }
-      const CADDR DObj &O = A.oloop[oi];
+      const CADDR DObj &O = AK->oloop[oi];
       const uint32_t i = O.index;
       const uint32_t type = O.type;
       bool ok = false;
@@ -551,8 +558,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     //      matter: the winner is the lexicographic minimum of (t, scene index). ----
     TSTAMP(t_oloop1);
     TACC(2, t_planes1, t_oloop1);
-    if (A.n_mesh != 0u) {
-      uint32_t t_pend = A.tlas_root;           // next top-level item: inner node or mesh leaf
+    if (AK->n_mesh != 0u) {
+      uint32_t t_pend = AK->tlas_root;           // next top-level item: inner node or mesh leaf
       uint32_t t_stack_v = 0, t_sp = 0;        // wave-uniform stack in the lanes of one VGPR
       for (;;) {
         TSTAMP(t_tl0);
@@ -565,14 +572,14 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           const float t_lim = anyhit_cast ? light_dist : best;
           // conservative box test constants, as in the per-mesh walk below (world-space margin
           // 2^-14 x G); recomputed per descent so that nothing stays live across the mesh code
-          const float gx = fmaxf(fabsf(A.tl_mn[0] - ro.x), fabsf(A.tl_mx[0] - ro.x));
-          const float gy = fmaxf(fabsf(A.tl_mn[1] - ro.y), fabsf(A.tl_mx[1] - ro.y));
-          const float gz = fmaxf(fabsf(A.tl_mn[2] - ro.z), fabsf(A.tl_mx[2] - ro.z));
+          const float gx = fmaxf(fabsf(AK->tl_mn[0] - ro.x), fabsf(AK->tl_mx[0] - ro.x));
+          const float gy = fmaxf(fabsf(AK->tl_mn[1] - ro.y), fabsf(AK->tl_mx[1] - ro.y));
+          const float gz = fmaxf(fabsf(AK->tl_mn[2] - ro.z), fabsf(AK->tl_mx[2] - ro.z));
           const float mw = fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f;
           const V3 t_ka = mk((ro.x + mw) * ria.x, (ro.y + mw) * ria.y, (ro.z + mw) * ria.z);
           const V3 t_kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);
           while (t_pend != TL_NONE && !(t_pend & BVH_LEAF_FLAG)) {
-            const CADDR DNode &N = A.nodes[A.tlas_begin + t_pend];
+            const CADDR DNode &N = A.nodes[AK->tlas_begin + t_pend];
             auto t_hits = [&](int c) -> mask_t {
               const float t1x = __builtin_fmaf(N.mn[0][c], ria.x, -t_ka.x), t2x = __builtin_fmaf(N.mx[0][c], ria.x, -t_kb.x);
               const float t1y = __builtin_fmaf(N.mn[1][c], ria.y, -t_ka.y), t2y = __builtin_fmaf(N.mx[1][c], ria.y, -t_kb.y);
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           }
         }
         if (t_pend == TL_NONE) break;
-        const CADDR DObj &O = A.meshes[t_pend & 0xFFFFFFu];
+        const CADDR DObj &O = AK->meshes[t_pend & 0xFFFFFFu];
         // advance first, so that `continue` below moves on to the next mesh
         if (t_sp != 0u) {
           t_sp--;
@@ -987,7 +994,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       // ---- hit record: hit point, normal (per primitive), material ----
       V3 normal = mk(0, 0, 0);
       if (was_hit) {
-        const CADDR DObj &H = A.objs[bobj];
+        const CADDR DObj &H = AK->objs[bobj];
         mat_i = H.mat;
         pos = vadd(ro, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
         { float unused_n; in_dn = vnormalized_n(in_d, unused_n); }
@@ -1002,7 +1009,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
           normal = mk(H.f[3], H.f[4], H.f[5]);
         } else {
           ro = pos;
-          normal = mk(A.gnorm[4 * btri + 0], A.gnorm[4 * btri + 1], A.gnorm[4 * btri + 2]);
+          normal = mk(AK->gnorm[4 * btri + 0], AK->gnorm[4 * btri + 1], AK->gnorm[4 * btri + 2]);
         }
       }
       if (first_trip) {
@@ -1019,7 +1026,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         act = ACT_UNWIND;
       } else {
         // phong prologue, shading.hpp:66-76
-        const CADDR DMat &M = A.mats[mat_i];
+        const CADDR DMat &M = AK->mats[mat_i];
         fin = vscale(mk(M.cx, M.cy, M.cz), ambient);
         { float unused_n; nn = vnormalized_n(normal, unused_n); }
         li = 0;
@@ -1031,7 +1038,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       float shadow_fac = 0.f;
       if (was_hit && best < light_dist) {
         // scenes without any transparency (the any-hit builds) need no material lookup here
-        const float trans = ANYHIT ? 0.0f : A.mats[A.objs[bobj].mat].transparency;
+        const float trans = ANYHIT ? 0.0f : AK->mats[AK->objs[bobj].mat].transparency;
         if (!ANYHIT) intensity += (1.0f - trans);
         if (ANYHIT || intensity >= 1.0f) { shadow_fac = 1.0f; done_shadow = true; }
         else {
@@ -1045,8 +1052,8 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
       if (done_shadow) {
         if (shadow_fac < 1.0f) {
           // shading.hpp:86-95
-          const CADDR DMat &M = A.mats[mat_i];
-          const CADDR DLight &Lg = A.lights[li];
+          const CADDR DMat &M = AK->mats[mat_i];
+          const CADDR DLight &Lg = AK->lights[li];
           const V3 diffuse = mk(M.cx, M.cy, M.cz);
           const V3 specular = vscale(diffuse, M.specular);  // default_schema.hpp:328
           const V3 color = mk(Lg.cx, Lg.cy, Lg.cz);
@@ -1077,9 +1084,9 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
     TSTAMP(t_cont_mid);
     TACC(7, t_loop1, t_cont_mid);
     if (act == ACT_LIGHT) {
-      if (li < A.n_light) {
+      if (li < AK->n_light) {
         // shading.hpp:79-85: direction/distance to light li, shadow ray from *hit
-        const CADDR DLight &Lg = A.lights[li];
+        const CADDR DLight &Lg = AK->lights[li];
         V3 direction;
         float distance;
         if (Lg.type == CTR_LIGHT_SUN) {  // default_schema.hpp:280-283
@@ -1102,9 +1109,9 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
 
     if (act == ACT_BOUNCE) {
       // shading.hpp:126-150 with rgb = fin
-      const CADDR DMat &M = A.mats[mat_i];
+      const CADDR DMat &M = AK->mats[mat_i];
       const float reflective = M.reflexivity, translucent = M.transparency;
-      const bool more = sp < A.bounces;  // `if constexpr (bounces != 0)`
+      const bool more = sp < AK->bounces;  // `if constexpr (bounces != 0)`
       const bool do_refl = more && (double)reflective >= 1e-6;
       const bool do_trans = more && (double)translucent >= 1e-6;
       if (do_refl || do_trans) {
@@ -1142,7 +1149,7 @@ __global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KA
         --sp;
         V3 rgb = mk(STK(sp, F_R), STK(sp, F_G), STK(sp, F_B));
         const uint32_t f_mat = __float_as_uint(STK(sp, F_MAT));
-        const CADDR DMat &FM = A.mats[f_mat & 0x3FFFFFFFu];
+        const CADDR DMat &FM = AK->mats[f_mat & 0x3FFFFFFFu];
         const float f_transl = FM.transparency;
         if ((f_mat >> 30) == 1u) {
           rgb = vadd(rgb, vscale(out_rgb, FM.reflexivity));  // shading.hpp:138
