@@ -37,7 +37,9 @@
 //
 // Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE correctly rounded on gfx950,
 // so every geometric quantity (depth, hit, normal, which object is hit) is bit-identical to the
-// host-compiled reference.  The specular term — the half vector's normalisation and pow() — uses
+// reference's headers COMPILED FOR THE HOST — std::min/max select semantics for the unqualified min/max
+// of the device code, no FMA contraction.  That, not a CUDA build (fminf/fmaxf-like overloads, --fmad),
+// is the parity target; profiles/r02/cuda_minmax_gap.txt counts what the difference touches.  The specular term — the half vector's normalisation and pow() — uses
 // v_rsq_f32 and exp2(e*log2(x)) in f32 by default (colour within 3e-6 of the reference) or IEEE
 // sqrt/division and f64 pow rounded once (CTR_VAR_EXACT_POW, bit-identical to glibc powf on every
 // tested pixel); it only feeds the colour.  Texture coordinates (atan2/asin, uv_for)
