@@ -301,10 +301,14 @@ def main():
         cj = args.counters_json or os.path.join(ROOT, "profiles", "r02", "counters.json")
         mj = os.path.join(ROOT, "profiles", "r02", "valu_mix.json")
         cnt = json.load(open(cj)) if os.path.exists(cj) else {}
-        mix = json.load(open(mj)) if os.path.exists(mj) else {}
-        mix = next(iter(mix.values())) if mix else {}
+        mixes = json.load(open(mj)) if os.path.exists(mj) else {}
+        # the instantiation the PMC pass saw ("render_kernel<107u>" -> mangled "...render_kernelILj107E...")
+        import re
+        m_ = re.search(r"render_kernel<(\d+)u>", cnt.get("kernel", ""))
+        mix = next((v for k, v in mixes.items() if m_ and f"render_kernelILj{m_.group(1)}E" in k), {})
         roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G SIMD-cycles/s", "frac": None,
-                "traffic": None, "kernel": "render_kernel<BVH|PREFILTER|ANYHIT|FASTPOW>", "kernel_ms_avg": kern_avg}
+                "traffic": None, "kernel": cnt.get("kernel", "render_kernel"), "kernel_ms_avg": kern_avg,
+                "kernel_variant_bits": "1 PREFILTER | 2 ANYHIT | 8 BVH | 32 FASTPOW | 64 built for 6 waves per SIMD"}
         if world == 1 and frames == 1 and cnt.get("workload") == workload and mix and kern_avg > 0:
             cost = mix["mean_issue_cycles"]
             # The kernel's CYCLE count per launch is what the counters pin (same code, same work); the clock the chip

@@ -22,6 +22,7 @@ VAR_NO_CLUSTER = 8
 VAR_STATS = 16
 VAR_EXACT_POW = 32
 VAR_NO_REORDER = 256
+VAR_NO_OCC6 = 512
 
 
 @contextlib.contextmanager

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -50,6 +51,9 @@ inline f3 cross(f3 a, f3 o) { return {a.y * o.z - a.z * o.y, a.z * o.x - a.x * o
 #endif
 #ifndef CTR_BVH_LEAF
 #define CTR_BVH_LEAF 4
+#endif
+#ifndef CTR_OCC6_MIN_TRIS
+#define CTR_OCC6_MIN_TRIS 1000  // scenes with at least this many mesh triangles use the 6-waves-per-SIMD build
 #endif
 #ifndef CTR_ORDER_PERIOD
 #define CTR_ORDER_PERIOD 8  // launches between rebuilds of the tile order
@@ -116,6 +120,11 @@ struct ctr_scene {
   bool need_cold = false;
   bool any_bounce = false;    // some material reflects or transmits (>= 1e-6): the recursion can go below depth 0
   size_t mesh_bytes = 0;      // triangles + BVH nodes
+  uint64_t mesh_tris = 0;     // triangles in meshes
+  static uint64_t occ6_min_tris() {
+    static const uint64_t v = [] { const char *e = getenv("CUTRACE_OCC6_MIN_TRIS"); return e ? (uint64_t)atoll(e) : (uint64_t)CTR_OCC6_MIN_TRIS; }();
+    return v;
+  }
   DCam cam{};                 // camera 0 (image size of every camera)
   DCam *d_cams = nullptr;     // device camera array (>= 1 entry)
   uint32_t n_cams = 0;
@@ -164,6 +173,8 @@ struct ctr_scene {
     if (all_opaque && !(user_variant & CTR_VAR_NO_ANYHIT) && !count) kv |= KV_ANYHIT;
     if (!(user_variant & CTR_VAR_NO_CLUSTER) && !count) kv |= KV_BVH;
     if (!(user_variant & CTR_VAR_EXACT_POW)) kv |= KV_FASTPOW;
+    // meshes of CTR_OCC6_MIN_TRIS triangles and more: the build for 6 waves per SIMD (render_kernel.hip KV_OCC6)
+    if (mesh_tris >= occ6_min_tris() && !(user_variant & CTR_VAR_NO_OCC6)) kv |= KV_OCC6;
     if (user_variant & CTR_VAR_STATS) kv = KV_STATS | (all_opaque && !(user_variant & CTR_VAR_NO_ANYHIT) ? KV_ANYHIT : 0u);
     if (count) kv = KV_PREFILTER | KV_COUNT;  // the counting launch walks like the reference (and wins over STATS)
     return kv;
@@ -613,6 +624,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->n_light = (uint32_t)lights.size();
   s->n_mat = (uint32_t)mats.size();
   s->has_mesh = has_mesh;
+  for (const ctr_scene::MeshGuard &g : guards) s->mesh_tris += g.tri_count;
   s->mesh_bytes = tris.size() * sizeof(DTri) + nodes.size() * sizeof(DNode) + nodes4.size() * sizeof(DNode4);
   s->all_opaque = all_opaque;
   s->need_cold = need_cold;

@@ -243,7 +243,7 @@ enum { M_RADIANCE = 0, M_SHADOW = 1, M_DONE = 2 };
 enum { ACT_NONE = 0, ACT_LIGHT = 1, ACT_BOUNCE = 2, ACT_UNWIND = 3 };
 
 template <uint32_t KV>
-__global__ __launch_bounds__(WG_THREADS, CTR_MIN_WAVES_EU) void render_kernel(KArgs A, float *__restrict__ depth_out,
+__global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) void render_kernel(KArgs A, float *__restrict__ depth_out,
                                                             float *__restrict__ color_out,
                                                             float *__restrict__ normal_out,
                                                             unsigned long long *__restrict__ counters) {
@@ -1476,5 +1476,13 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
   if (L.variant & KV_STATS)
     return (L.variant & KV_ANYHIT) ? launch<KV_BVH | KV_PREFILTER | KV_ANYHIT | KV_FASTPOW | KV_STATS>(L, s)
                                    : launch<KV_BVH | KV_PREFILTER | KV_FASTPOW | KV_STATS>(L, s);
+  // KV_OCC6: the same kernel compiled for 6 waves per SIMD (80 VGPRs, ~10 of them spilled to scratch once per
+  // trip) instead of 5 (87, none): worth it where the mesh data exceed the scalar cache many times over and a
+  // wave mostly waits for L2 (ctr_api.cpp picks it by triangle count); only the shipped default variant has it
+  // (and only when 24 waves' recursion stacks fit the CU's 160 KB of LDS: bounces <= 6 without cold frames)
+  const size_t stack_bytes = (size_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1) * (L.need_cold_frames ? 10u : 4u) * 64 * sizeof(float);
+  if ((L.variant & KV_OCC6) && stack_bytes * 24 <= 160u * 1024u &&
+      (L.variant & (KV_PREFILTER | KV_ANYHIT | KV_BVH | KV_FASTPOW)) == (KV_PREFILTER | KV_ANYHIT | KV_BVH | KV_FASTPOW))
+    return launch<KV_OCC6 | KV_PREFILTER | KV_ANYHIT | KV_BVH | KV_FASTPOW>(L, s);
   return (L.variant & KV_FASTPOW) ? launch_main<KV_FASTPOW>(L, s) : launch_main<0>(L, s);
 }

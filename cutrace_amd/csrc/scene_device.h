@@ -102,6 +102,7 @@ enum : uint32_t {
   KV_BVH = 8u,         // walk each mesh through its BVH instead of linearly
   KV_STATS = 16u,      // diagnostic: wave-level work counters into counters[4..9]
   KV_FASTPOW = 32u,    // specular pow() as exp2(e*log2(x)) in f32 instead of f64 pow
+  KV_OCC6 = 64u,       // compiled for 6 waves per SIMD instead of 5 (large meshes: latency-bound on scalar-cache misses)
 };
 
 struct DRows {

@@ -20,5 +20,5 @@ run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
 cd $REPO
 python3 scripts/pmc_summary.py gpurun_out/pmc_${TAG}_* > gpurun_out/pmc_${TAG}_summary.txt 2>&1
-python3 scripts/pmc_counters.py gpurun_out/pmc_${TAG} "render_kernel<43u>" "${WORKLOAD:-bunny.json@1920x1080b5}" gpurun_out/pmc_${TAG}_counters.json
+python3 scripts/pmc_counters.py gpurun_out/pmc_${TAG} "render_kernel<" "${WORKLOAD:-bunny.json@1920x1080b5}" gpurun_out/pmc_${TAG}_counters.json
 cat gpurun_out/pmc_${TAG}_summary.txt

@@ -13,17 +13,22 @@ prefix, kern, workload, out = sys.argv[1:5]
 
 
 def load(name):
+    global kernel_name
     rows = []
     for f in glob.glob(os.path.join(f"{prefix}_{name}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
                 rows.append(r)
+                kernel_name = r["Kernel_Name"]
     per = {}
     for r in rows:
         d = per.setdefault(int(r["Dispatch_Id"]), {"t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     ids = sorted(per)[1:] or sorted(per)   # drop the first (image-order) launch
     return [per[i] for i in ids]
+
+
+kernel_name = ""
 
 
 def mean(rows, key):
@@ -36,7 +41,8 @@ cyc = mean(grbm, "GRBM_GUI_ACTIVE") / 8.0
 t_ns = mean(grbm, "t")
 fk, wk = mean(fetch, "FETCH_SIZE"), mean(write, "WRITE_SIZE")
 res = {
-    "workload": workload, "kernel": kern, "dispatches_averaged": len(sq1),
+    "workload": workload, "kernel": kernel_name.split("(")[0].split("::")[-1] if kernel_name else kern,
+    "dispatches_averaged": len(sq1),
     "valu_insts_per_launch": mean(sq1, "SQ_INSTS_VALU"), "salu_insts_per_launch": mean(sq1, "SQ_INSTS_SALU"),
     "smem_insts_per_launch": mean(sq1, "SQ_INSTS_SMEM"), "waves_per_launch": mean(sq1, "SQ_WAVES"),
     "wave_quadcycles_per_launch": mean(sq1, "SQ_WAVE_CYCLES"), "wait_any_quadcycles": mean(sq1, "SQ_WAIT_ANY"),
