@@ -318,19 +318,24 @@ int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows
   // ---- 2. one gather to device 0 ----
   if (n > 1) {
     if (m->use_rccl) {
+      // (no early return between GroupStart and GroupEnd: an open group would poison every later call)
       ncclResult_t r = g_rccl.GroupStart();
-      for (uint32_t p = 1; p < n && r == ncclSuccess; p++) {
+      hipError_t he = hipSuccess;
+      for (uint32_t p = 1; p < n && r == ncclSuccess && he == hipSuccess; p++) {
         Part &P = m->parts[p];
         const size_t cnt = (size_t)(7 * P.rows * w);
         if (!cnt) continue;
-        MHIP(hipSetDevice(P.device));
+        he = hipSetDevice(P.device);
+        if (he != hipSuccess) break;
         r = g_rccl.Send(P.buf, cnt, ncclFloat, 0, P.comm, P.stream);
         if (r != ncclSuccess) break;
-        MHIP(hipSetDevice(P0.device));
+        he = hipSetDevice(P0.device);
+        if (he != hipSuccess) break;
         r = g_rccl.Recv(P.gathered, cnt, ncclFloat, (int)p, P0.comm, P0.stream);
       }
-      ncclResult_t r2 = g_rccl.GroupEnd();
+      const ncclResult_t r2 = g_rccl.GroupEnd();
       if (r == ncclSuccess) r = r2;
+      if (he != hipSuccess) return mfail(CTR_E_HIP_BASE + (int)he, std::string("RCCL gather: ") + hipGetErrorString(he));
       if (r != ncclSuccess) return mfail(CTR_E_HIP_BASE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r));
     } else {
       MHIP(hipSetDevice(P0.device));

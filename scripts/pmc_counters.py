@@ -8,7 +8,7 @@ scene's first launch, in image order — is left out):
   HBM bytes                    2 x FETCH_SIZE + WRITE_SIZE KiB (gfx950: FETCH_SIZE counts 64 B per 128-B request;
                                MI355X_MICROARCH.md §HBM), each from its own pass
 usage: pmc_counters.py <dir-prefix> <kernel-substring> <workload> <out.json>"""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 prefix, kern, workload, out = sys.argv[1:5]
 
 
@@ -41,7 +41,7 @@ cyc = mean(grbm, "GRBM_GUI_ACTIVE") / 8.0
 t_ns = mean(grbm, "t")
 fk, wk = mean(fetch, "FETCH_SIZE"), mean(write, "WRITE_SIZE")
 res = {
-    "workload": workload, "kernel": kernel_name.split("(")[0].split("::")[-1] if kernel_name else kern,
+    "workload": workload, "kernel": (re.search(r"render_kernel<\d+u>", kernel_name) or [kern])[0] if kernel_name else kern,
     "dispatches_averaged": len(sq1),
     "valu_insts_per_launch": mean(sq1, "SQ_INSTS_VALU"), "salu_insts_per_launch": mean(sq1, "SQ_INSTS_SALU"),
     "smem_insts_per_launch": mean(sq1, "SQ_INSTS_SMEM"), "waves_per_launch": mean(sq1, "SQ_WAVES"),
