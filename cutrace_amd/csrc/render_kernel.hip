@@ -12,18 +12,24 @@
 //    a wave are spatially coherent and the scene is tiny and read-only, so EVERY scene read in the
 //    hot loops has a wave-uniform address: planes, objects, BVH nodes and triangles are fetched
 //    with scalar loads (one 64-byte record = one s_load_dwordx16) into SGPRs and feed the VALU as
-//    scalar operands — no VGPRs, no LDS bandwidth, no bank conflicts.
+//    scalar operands — no VGPRs, no LDS bandwidth, no bank conflicts.  (Measured, scripts/valu_issue.hip:
+//    a VALU instruction with an SGPR operand issues at half rate, 4.1 cycles per wave64 instruction
+//    against 2.2 — still the cheapest way to get a wave-uniform record to the lanes; a packed
+//    instruction with an SGPR-PAIR operand does two such operations in the same 4.1 cycles, which is
+//    why nodes, planes and triangles store their coordinates as aligned pairs.)
 //  * the recursion of ray_color (template depth `bounces`) becomes an explicit per-lane state
 //    machine: every trip of the outer loop performs exactly ONE nearest-hit cast for every live
 //    lane, whatever that lane needs it for (primary, reflection, pass-through or a shadow-loop
 //    iteration).  The expensive part (plane / object / BVH / triangle loops) is always executed by
 //    a converged wave; only the cheap continuation logic diverges.  Suspended activations live in
-//    an LDS stack [frame][field][lane]; no scratch memory.
+//    an LDS stack [frame][field][lane] (4 dwords per frame); no scratch memory in the default build.
 //  * hot-loop conditions are 64-bit lane masks (v_cmp into SGPR pairs, combined on the scalar
 //    unit), not per-lane booleans.
 //  * per mesh: the reference's AABB test decided with 1-ulp reciprocals except on borderline lanes;
-//    a BVH (inner nodes hold both children's boxes, wave-uniform stack in the lanes of one VGPR)
-//    walked by the whole wave, both child boxes per node tested with packed FMAs; per triangle a
+//    a four-wide BVH (a node holds its four children's boxes, wave-uniform stack in the lanes of one
+//    VGPR) walked by the whole wave, two child boxes per packed FMA; triangles whose plane contains an
+//    eye or a light are additionally handed to every lane (guard records: the one regime where culling
+//    could differ from the linear walk, ctr_api.cpp refresh_linear_meshes); per triangle a
 //    conservative FMA prefilter for the whole wave (barycentrics, then — only if a lane survives —
 //    the ray parameter), then the reference's exact Cramer/determinant test
 //    (default_schema.hpp:57-78) in the reference's operation order for surviving lanes, its three
@@ -34,12 +40,18 @@
 //  * the duplicated primary cast (kernel.hpp:52 + shading.hpp:123) is done once.
 //  * tiles are dispatched expensive-first from the costs the previous launch recorded (after_render),
 //    which removes the tail of slow waves at the end of a frame.
+//  * arguments that only the continuation or the start of a cast needs are re-read from the kernarg
+//    segment instead of living in SGPRs across the inner loops (no spill reloads by v_readlane); the
+//    build avoids SLP vectorisation (compiler-made v_pk_* cost more in shuffles than they save).
+//  * two builds of the default variant: 87 VGPRs = 5 waves per SIMD, and (KV_OCC6) 80 VGPRs with ten
+//    spilled to scratch = 6 waves, picked for scenes with >= 1000 mesh triangles.
 //
 // Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE correctly rounded on gfx950,
 // so every geometric quantity (depth, hit, normal, which object is hit) is bit-identical to the
 // reference's headers COMPILED FOR THE HOST — std::min/max select semantics for the unqualified min/max
 // of the device code, no FMA contraction.  That, not a CUDA build (fminf/fmaxf-like overloads, --fmad),
-// is the parity target; profiles/r02/cuda_minmax_gap.txt counts what the difference touches.  The specular term — the half vector's normalisation and pow() — uses
+// is the parity target; profiles/r02/cuda_minmax_gap.txt counts what the difference touches.
+// The specular term — the half vector's normalisation and pow() — uses
 // v_rsq_f32 and exp2(e*log2(x)) in f32 by default (colour within 3e-6 of the reference) or IEEE
 // sqrt/division and f64 pow rounded once (CTR_VAR_EXACT_POW, bit-identical to glibc powf on every
 // tested pixel); it only feeds the colour.  Texture coordinates (atan2/asin, uv_for)
