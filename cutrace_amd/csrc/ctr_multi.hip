@@ -211,8 +211,21 @@ int ctr_multi_create(const ctr_scene_desc *desc, const int *devices, int n_devic
   }
   hipError_t e = hipHostMalloc((void **)&m->h_counters, sizeof(unsigned long long) * 16 * n_devices, hipHostMallocDefault);
   if (e != hipSuccess) { ctr_multi_destroy(m); return mfail(CTR_E_HIP_BASE + (int)e, "ctr_multi_create: hipHostMalloc"); }
+  const char *force = getenv("CUTRACE_MULTI_TRANSPORT");  // "peer" forces hipMemcpyPeerAsync; "rccl-self" see below
+  if (n_devices == 1 && force && !strcmp(force, "rccl-self") && g_rccl.load()) {
+    // Self-test of the RCCL plumbing on a one-GPU box: a one-rank communicator, and the frame travels through one
+    // grouped ncclSend / ncclRecv to and from rank 0 itself (library load, communicator, group call, stream order).
+    ncclComm_t c = nullptr;
+    ncclResult_t r = g_rccl.CommInitAll(&c, 1, devices);
+    if (r == ncclSuccess) {
+      m->parts[0].comm = c;
+      m->use_rccl = true;
+      m->transport = "rccl-self";
+    } else {
+      mfail(CTR_E_HIP_BASE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+    }
+  }
   if (n_devices > 1) {
-    const char *force = getenv("CUTRACE_MULTI_TRANSPORT");  // "peer" forces hipMemcpyPeerAsync (diagnostic)
     if (distinct && !(force && !strcmp(force, "peer")) && g_rccl.load()) {
       std::vector<ncclComm_t> comms(n_devices);
       ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_devices, devices);
@@ -349,9 +362,23 @@ int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows
       }
     }
   }
+  const float *self_result = nullptr;
+  if (n == 1 && m->use_rccl && fpx) {  // "rccl-self": the frame goes through RCCL once, rank 0 -> rank 0
+    if (!P0.gathered) {
+      MHIP(hipSetDevice(P0.device));
+      MHIP(hipMalloc((void **)&P0.gathered, sizeof(float) * 7 * m->cap_px));
+    }
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r == ncclSuccess) r = g_rccl.Send(P0.buf, (size_t)(7 * fpx), ncclFloat, 0, P0.comm, P0.stream);
+    if (r == ncclSuccess) r = g_rccl.Recv(P0.gathered, (size_t)(7 * fpx), ncclFloat, 0, P0.comm, P0.stream);
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return mfail(CTR_E_HIP_BASE, std::string("RCCL self send/recv: ") + g_rccl.GetErrorString(r));
+    self_result = P0.gathered;
+  }
   // ---- 3. re-interleave on device 0, 4. one D2H ----
   MHIP(hipSetDevice(P0.device));
-  const float *result = P0.buf;  // n == 1: the compact buffer IS the frame
+  const float *result = self_result ? self_result : P0.buf;  // n == 1: the compact buffer IS the frame
   if (n > 1 && fpx) {
     Reint R{};
     for (uint32_t p = 0; p < n; p++) {

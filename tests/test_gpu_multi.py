@@ -133,3 +133,22 @@ def test_nccl_backend_world_one(ca):
         assert float(t[0]) == 1.0
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_plumbing_self_send_recv(ca):
+    """The RCCL code of ctr_render_multi on the one GPU there is: librccl is dlopen'ed, a one-rank communicator
+    created, and the rendered frame goes through ONE grouped ncclSend / ncclRecv (rank 0 to rank 0) before it is
+    delivered — the same calls, stream order and buffers an N-GPU group uses, minus the second device."""
+    s = load_scene(ca, "bunny", 256, 144)
+    want = ca.DeviceScene(s).render(bounces=5)
+    os.environ["CUTRACE_MULTI_TRANSPORT"] = "rccl-self"
+    try:
+        m = ca.MultiScene(s, [0])
+    finally:
+        del os.environ["CUTRACE_MULTI_TRANSPORT"]
+    if m.transport != "rccl-self":
+        pytest.skip("librccl.so could not be loaded on this box")
+    got = m.render(bounces=5)
+    assert _same(got, want)
+    assert _same(m.render(bounces=5), want)
+    m.close()
