@@ -474,3 +474,31 @@ def test_exact_sqrt_and_reciprocal_shortcut_is_exhaustively_correct(ca):
     n = C.c_uint64(1)
     assert _lib.hip_lib().ctr_selftest_exact_math(C.byref(n)) == 0
     assert n.value == 0, f"{n.value} of {6 * 2**23} (sqrt, 1/sqrt) pairs differ from sqrtf / IEEE division"
+
+
+def test_six_wave_build_and_pinned_frames_change_nothing(ca):
+    """The build compiled for 6 waves per SIMD (picked for >= 1000 mesh triangles; ten VGPRs spilled to scratch) against
+    the 5-wave build, and delivery into a page-locked frame block (one DMA) against pageable buffers: same bytes."""
+    s = load_scene(ca, "bunny")            # 1000 triangles: the 6-wave build by default
+    ds = ca.DeviceScene(s)
+    a = ds.render(bounces=5)
+    ds.set_variant(ca.VAR_NO_OCC6)
+    b = ds.render(bounces=5)
+    ds.set_variant(0)
+    c = ds.render(bounces=5, pinned=True)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(a[k], b[k]), k
+        assert same_bits(a[k], c[k]), k
+    assert a["ray_count"] == b["ray_count"] == c["ray_count"] == 64278888
+    assert a["max_depth"] == b["max_depth"] == c["max_depth"]
+    # a row subset into the same (larger) pinned block, then the diagnostics
+    d = ds.render(bounces=5, rows=(0, 1080, 8, 3, 8), pinned=True)
+    ys = [y for y in range(1080) if (y // 8) % 8 == 3]
+    assert same_bits(d["depth"], a["depth"][ys]) and same_bits(d["color"], a["color"][ys])
+    costs = ds.tile_costs()
+    assert costs.size == 240 * ((len(ys) + 7) // 8) and costs.min() > 0
+    ds.set_variant(ca.VAR_STATS)
+    ds.render(bounces=5)
+    cnt = ds.last_counters()
+    assert int(cnt[0]) == 64278888 and int(cnt[4]) == 972000     # 30 trips for each of the 32 400 waves
+    assert 0 < int(cnt[10]) <= 64 * int(cnt[5]) and 0 < int(cnt[11]) <= 64 * int(cnt[6]) and 0 < int(cnt[12]) <= 64 * int(cnt[7])
