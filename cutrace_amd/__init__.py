@@ -23,6 +23,7 @@ VAR_STATS = 16
 VAR_EXACT_POW = 32
 VAR_NO_REORDER = 256
 VAR_NO_OCC6 = 512
+VAR_NO_DIRECT = 1024
 
 
 @contextlib.contextmanager
@@ -275,11 +276,27 @@ class MultiScene:
             raise RuntimeError("ctr_multi_set_size failed")
         self.w, self.h = w, h
 
-    def render(self, fudge=1e-3, bounces=5, block_rows=8):
+    def render(self, fudge=1e-3, bounces=5, block_rows=8, pinned=False):
+        """pinned=True: the buffers are views of a page-locked frame block of this group (valid until the next pinned
+        render / close); device 0 then writes the frame into it directly."""
         L = _lib.hip_lib()
-        depth = np.empty((self.h, self.w), np.float32)
-        color = np.empty((self.h, self.w, 3), np.float32)
-        normal = np.empty((self.h, self.w, 3), np.float32)
+        if pinned:
+            px = self.w * self.h
+            if getattr(self, "_pin_px", 0) != px:
+                self._free_pinned()
+                d, c, n = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+                if L.ctr_frame_alloc(px, C.byref(d), C.byref(c), C.byref(n)):
+                    raise RuntimeError("ctr_frame_alloc failed")
+                self._pin_ptr, self._pin_px = d, px
+                self._pin = np.ctypeslib.as_array(d, shape=(7 * px,))
+            blk = self._pin
+            depth = blk[:px].reshape(self.h, self.w)
+            color = blk[px:4 * px].reshape(self.h, self.w, 3)
+            normal = blk[4 * px:7 * px].reshape(self.h, self.w, 3)
+        else:
+            depth = np.empty((self.h, self.w), np.float32)
+            color = np.empty((self.h, self.w, 3), np.float32)
+            normal = np.empty((self.h, self.w, 3), np.float32)
         stats = RenderStats()
         st = L.ctr_render_multi(self._h, C.c_float(fudge), bounces, block_rows, depth.ctypes.data, color.ctypes.data,
                                 normal.ctypes.data, C.byref(stats))
@@ -291,8 +308,15 @@ class MultiScene:
                     total_ms=stats.total_ms, max_depth=float(stats.max_depth), rows=int(stats.rows),
                     kernel_ms_per_device=list(ms))
 
+    def _free_pinned(self):
+        if getattr(self, "_pin_px", 0):
+            self._pin = None
+            _lib.hip_lib().ctr_frame_free(self._pin_ptr)
+            self._pin_px = 0
+
     def close(self):
         if self._h:
+            self._free_pinned()
             _lib.hip_lib().ctr_multi_destroy(self._h)
             self._h = None
 

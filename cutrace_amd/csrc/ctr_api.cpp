@@ -154,6 +154,8 @@ struct ctr_scene {
   unsigned long long *d_counters = nullptr;
   unsigned long long *d_shards = nullptr;  // CTR_SHARDS x CTR_SHARD_WORDS, zero between launches
   size_t out_px = 0;
+  uint32_t *d_groups = nullptr;  // host delivery: one completion counter per group of tiles (render_kernel.hip)
+  size_t groups_cap = 0;
   // tile scheduling feedback (include/cutrace_amd.h "Tile scheduling")
   uint32_t *d_cost = nullptr, *d_order = nullptr;
   uint32_t order_age = 0;  // launches of the current shape
@@ -274,7 +276,8 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
   }
   const uint64_t key[6] = {n, ((uint64_t)L.w << 32) | L.h, ((uint64_t)L.rows.row_begin << 32) | L.rows.row_end,
                            ((uint64_t)L.rows.block_rows << 32) | L.rows.n_parts,
-                           ((uint64_t)L.rows.part << 32) | L.rows.part_stride, L.n_frames};
+                           ((uint64_t)L.rows.part << 32) | L.rows.part_stride,
+                           ((uint64_t)(L.group_done ? 1u : 0u) << 32) | L.n_frames};  // (host delivery orders tiles by group)
   const bool same = s->order_valid && memcmp(key, s->order_key, sizeof(key)) == 0;
   // (a shape's first launch runs in image order: an a-priori estimate — tiles whose primary rays meet the box
   //  of a mesh / sphere, computed and sorted by a pre-pass — was built and measured in round 2: the expensive
@@ -414,6 +417,17 @@ bool is_pinned(const void *p) {
     return false;
   }
   return at.type == hipMemoryTypeHost;
+}
+
+// the device's address of page-locked host memory (false: not mapped for this device)
+bool device_view(float *host, float **dev) {
+  void *d = nullptr;
+  if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess || !d) {
+    (void)hipGetLastError();
+    return false;
+  }
+  *dev = (float *)d;
+  return true;
 }
 
 }  // namespace
@@ -710,7 +724,7 @@ void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_nodes4, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
-                  (void *)s->d_out, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
+                  (void *)s->d_out, (void *)s->d_groups, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
     if (p) (void)hipFree(p);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -809,12 +823,38 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   fill_launch(s, L);
   if ((st = make_rows(s, rows, L.rows))) return st;
   const size_t px = (size_t)L.rows.n_rows * s->cam.w;
-  if ((st = ensure_outputs(s, px ? px : 1))) return st;
+  // Page-locked destinations (ctr_frame_alloc, hipHostMalloc, mapped hipHostRegister) are visible to the device:
+  // the kernel then delivers the frame ITSELF, group of tiles by group of tiles while it renders (render_kernel.hip
+  // "Host delivery"), so the 28 bytes per pixel cross PCIe underneath the rendering instead of in a DMA after it.
+  // Any other destination: device buffers + copies, below.
+  float *zd = nullptr, *zc = nullptr, *zn = nullptr;
+  const bool direct = px && depth && color3 && normal3 && !count && !(s->user_variant & (CTR_VAR_NO_DIRECT | CTR_VAR_STATS)) &&
+                      ctr_host_delivery_available(s->kernel_variant(false)) &&
+                      is_pinned(depth) && is_pinned(depth + px - 1) && is_pinned(color3) && is_pinned(color3 + 3 * px - 1) &&
+                      is_pinned(normal3) && is_pinned(normal3 + 3 * px - 1) && device_view(depth, &zd) &&
+                      device_view(color3, &zc) && device_view(normal3, &zn);
+  const size_t spx = direct ? (size_t)ctr_staging_pixels(L) : (px ? px : 1);  // pixels per output buffer on the device
+  if ((st = ensure_outputs(s, spx))) return st;
   L.fudge = fudge;
   L.bounces = bounces;
   L.depth = s->d_out;
-  L.color = s->d_out + px;
-  L.normal = s->d_out + 4 * px;
+  L.color = s->d_out + spx;
+  L.normal = s->d_out + 4 * spx;
+  if (direct) {
+    const size_t groups = (size_t)ctr_staging_groups(L);
+    if (groups > s->groups_cap) {
+      if (s->d_groups) (void)hipFree(s->d_groups);
+      s->d_groups = nullptr;
+      s->groups_cap = 0;
+      HIP_TRY(hipMalloc((void **)&s->d_groups, groups * sizeof(uint32_t)));
+      HIP_TRY(hipMemset(s->d_groups, 0, groups * sizeof(uint32_t)));  // (every launch leaves them zeroed)
+      s->groups_cap = groups;
+    }
+    L.host_depth = zd;
+    L.host_color = zc;
+    L.host_normal = zn;
+    L.group_done = s->d_groups;
+  }
   L.counters = s->d_counters;
   L.variant = s->kernel_variant(count);
   if ((st = attach_order(s, L, count))) return st;
@@ -827,7 +867,7 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   // (ctr_frame_alloc, hipHostMalloc, hipHostRegister) are written by direct DMA queued behind the kernel:
   // ONE transfer when the three buffers are the consecutive parts of one block, else one per buffer.
   // Pageable destinations go through the runtime's staged copy, one call per buffer.
-  if (px) {
+  if (px && !direct) {
     const bool packed = depth && color3 == depth + px && normal3 == color3 + 3 * px;
     if (packed && is_pinned(depth) && is_pinned(normal3 + 3 * px - 1)) {
       HIP_TRY(hipMemcpyAsync(depth, s->d_out, sizeof(float) * 7 * px, hipMemcpyDeviceToHost, nullptr));

@@ -132,9 +132,22 @@ bool pinned(const void *p) {
   return at.type == hipMemoryTypeHost;
 }
 
+// the device's address of a page-locked host range (nullptr: not page-locked, or not mapped for the current device)
+float *device_view(float *host, size_t n) {
+  if (!host || !n || !pinned(host) || !pinned(host + n - 1)) return nullptr;
+  void *d = nullptr;
+  if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return (float *)d;
+}
+
 }  // namespace
 
 struct ctr_multi {
+  uint32_t variant = 0;
+  double single_ms = -1.0;    // kernel ms of the last call when it went through ctr_render (one device), else < 0
   std::vector<Part> parts;
   uint64_t w = 0, h = 0;
   uint64_t cap_px = 0;        // pixels each compact buffer can hold
@@ -300,6 +313,7 @@ int ctr_multi_set_size(ctr_multi *m, uint64_t w, uint64_t h) {
 int ctr_multi_set_variant(ctr_multi *m, uint32_t bits) {
   if (!m) return mfail(CTR_E_INVALID, "null group");
   for (Part &P : m->parts) ctr_set_variant(P.scene, bits);
+  m->variant = bits;
   return CTR_OK;
 }
 
@@ -313,6 +327,23 @@ int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows
   if (st) return st;
   const uint64_t w = m->w, h = m->h, fpx = w * h;
   Part &P0 = m->parts[0];
+  // Page-locked destinations are written by device 0 itself: through ctr_render's host delivery when there is one
+  // device, by the re-interleave kernel (whole rows, 16 bytes per lane) otherwise — no frame-sized D2H after it.
+  MHIP(hipSetDevice(P0.device));
+  float *zd = nullptr, *zc = nullptr, *zn = nullptr;
+  const bool direct = fpx && !(m->variant & CTR_VAR_NO_DIRECT) && (zd = device_view(depth, fpx)) &&
+                      (zc = device_view(color3, 3 * fpx)) && (zn = device_view(normal3, 3 * fpx));
+  m->single_ms = -1.0;
+  if (direct && n == 1 && !m->use_rccl) {  // one device: ctr_render's own host delivery
+    ctr_render_stats one{};
+    if ((st = ctr_render(P0.scene, fudge, bounces, nullptr, depth, color3, normal3, &one))) return st;
+    m->single_ms = one.kernel_ms;
+    if (stats) {
+      *stats = one;
+      stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    }
+    return CTR_OK;
+  }
   // ---- 1. every device renders its interleaved row blocks into its compact buffer ----
   for (uint32_t p = 0; p < n; p++) {
     Part &P = m->parts[p];
@@ -392,11 +423,12 @@ int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows
     R.block_rows = (uint32_t)block_rows;
     R.w = (uint32_t)w;
     R.h = (uint32_t)h;
-    hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, P0.stream, R, m->frame, m->frame + fpx, m->frame + 4 * fpx);
+    if (direct) hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, P0.stream, R, zd, zc, zn);
+    else hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, P0.stream, R, m->frame, m->frame + fpx, m->frame + 4 * fpx);
     MHIP(hipGetLastError());
     result = m->frame;
   }
-  if (fpx) {
+  if (fpx && !(direct && n > 1)) {
     const bool packed = depth && color3 == depth + fpx && normal3 == color3 + 3 * fpx;
     if (packed && pinned(depth) && pinned(normal3 + 3 * fpx - 1)) {
       MHIP(hipMemcpyAsync(depth, result, sizeof(float) * 7 * fpx, hipMemcpyDeviceToHost, P0.stream));
@@ -455,6 +487,10 @@ int ctr_reinterleave_device(const ctr_reint_part *parts, uint32_t n_parts, uint6
 
 int ctr_multi_kernel_ms(ctr_multi *m, double *ms_per_device, int capacity) {
   if (!m || !ms_per_device) return mfail(CTR_E_INVALID, "ctr_multi_kernel_ms: null argument");
+  if (m->single_ms >= 0.0 && capacity > 0) {
+    ms_per_device[0] = m->single_ms;
+    return CTR_OK;
+  }
   for (int p = 0; p < (int)m->parts.size() && p < capacity; p++) {
     float ms = 0.f;
     MHIP(hipSetDevice(m->parts[p].device));

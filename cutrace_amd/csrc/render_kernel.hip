@@ -249,7 +249,22 @@ struct KArgs {
                       // material reflects or transmits: ray_color then never recurses)
   const CADDR uint32_t *order;  // dispatch slot -> wave (tile) index, or null = identity
   uint32_t *cost;               // per wave (tile): shader-clock ticks it took, or null
+  // "Host delivery" (below): null group_done = the outputs are written in place
+  float *host_depth, *host_color, *host_normal;
+  uint32_t *group_done;
 };
+
+// ---- Host delivery ----
+// ctr_render hands the kernel page-locked HOST buffers.  Storing the pixels there tile by tile works (the memory is
+// device-visible) but reaches PCIe as 32- and 96-byte runs: 43 GB/s for the stores alone, where one DMA of the frame
+// makes 56 (scripts/pcie_store.hip).  So the tiles go to a tile-major staging area in device memory, and the wave
+// that completes a GROUP of 64/TW horizontally adjacent tiles (64 x TH pixels; a counter per group) copies the
+// group into the host buffers in runs of 256 / 768 bytes — the DMA's rate, but spread over the whole launch instead
+// of after it.  The order the tiles are dispatched in keeps the tiles of a group together (order_block).
+constexpr uint32_t GROUP_TILES = 64 / TW;
+#ifndef CTR_CHEAP_FIRST_PCT
+#define CTR_CHEAP_FIRST_PCT 25u  // order_block_groups: share of the groups, the cheapest, dispatched before the dear ones
+#endif
 
 enum { M_RADIANCE = 0, M_SHADOW = 1, M_DONE = 2 };
 enum { ACT_NONE = 0, ACT_LIGHT = 1, ACT_BOUNCE = 2, ACT_UNWIND = 3 };
@@ -269,6 +284,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   constexpr bool STATS = (KV & KV_STATS) != 0;
 #endif
   constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
+  constexpr bool HOSTOUT = (KV & KV_HOSTOUT) != 0;  // "Host delivery"
   // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast,
   // and how many of the 64 lanes had a use for the wave-level work: [6] lanes whose ray meets one of the
@@ -328,9 +344,23 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   // kernel.hpp:54 (compact buffer).  Recomputed from the lane id at its three uses rather than kept
   // in two VGPRs for the whole wave: registers, not instructions, are what this kernel is short of.
   const uint32_t tile_px0 = ty * TH * w + tx * TW;  // wave-uniform
+  // a pixel's three floats: in place, or — staged — written THROUGH to memory (agent scope), because the wave that
+  // copies the group to the host usually runs on another XCD, whose L2 is not coherent with this one
+  auto store3 = [&](float *__restrict__ out, size_t px_id, V3 v) {
+    if (HOSTOUT) {
+      __hip_atomic_store(out + 3 * px_id + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(out + 3 * px_id + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(out + 3 * px_id + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      out[3 * px_id + 0] = v.x;
+      out[3 * px_id + 1] = v.y;
+      out[3 * px_id + 2] = v.z;
+    }
+  };
   auto px_index = [&]() -> size_t {
     uint32_t l = lane;
     asm volatile("" : "+v"(l));  // recompute here: hoisted out of the loop the addresses would be spilled to scratch
+    if (HOSTOUT) return (size_t)wave * 64u + l;  // tile-major staging ("Host delivery")
     return (size_t)frame * A.frame_stride_px + (size_t)(tile_px0 + (l / TW) * w + (l % TW));
   };
 
@@ -1029,10 +1059,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       if (first_trip) {
         // kernel.hpp:55-56 (depth = +inf, normal = 0 on a miss)
         const size_t px_id = px_index();
-        depth_out[px_id] = best;
-        normal_out[3 * px_id + 0] = normal.x;
-        normal_out[3 * px_id + 1] = normal.y;
-        normal_out[3 * px_id + 2] = normal.z;
+        if (HOSTOUT) __hip_atomic_store(depth_out + px_id, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else depth_out[px_id] = best;
+        store3(normal_out, px_id, normal);
         first_depth = best;
       }
       if (!was_hit) {
@@ -1154,9 +1183,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       for (;;) {
         if (sp == 0) {
           const size_t px_id = px_index();
-          color_out[3 * px_id + 0] = out_rgb.x;
-          color_out[3 * px_id + 1] = out_rgb.y;
-          color_out[3 * px_id + 2] = out_rgb.z;
+          store3(color_out, px_id, out_rgb);
           mode = M_DONE;
           break;
         }
@@ -1199,6 +1226,73 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     TACC(8, t_cont_mid, t_cont1);
   }
 #undef STK
+
+  if (HOSTOUT) {
+    const CADDR KArgs *AE = (const CADDR KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(AE));  // the kernel arguments once more (see AK): none of this is worth an SGPR across the loop
+    // "Host delivery": this tile is complete; the wave that completes its group copies the group to the host
+    const uint32_t e_w = AE->w, e_tiles_x = (e_w + TW - 1) / TW, e_ty = wave / e_tiles_x, e_tx = wave - e_ty * e_tiles_x;
+    const uint32_t groups_x = (e_tiles_x + GROUP_TILES - 1) / GROUP_TILES;
+    const uint32_t gx = e_tx / GROUP_TILES, t0 = gx * GROUP_TILES;
+    const uint32_t nt = e_tiles_x - t0 < GROUP_TILES ? e_tiles_x - t0 : GROUP_TILES;
+    uint32_t *const done = AE->group_done + (e_ty * groups_x + gx);
+    // The tile's pixels were written through (store3) and have arrived when the counter is incremented: an agent-
+    // scope release fence here would write this XCD's whole L2 back, and the acquire below invalidate it, once per
+    // wave — 3 ms per frame, measured.  The copy reads with agent-scope loads, which do not hit a stale L2 line.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t old = 0;
+    if (lane == 0) old = atomicAdd(done, 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old == nt - 1) {
+      if (lane == 0) *done = 0u;  // every tile of the group has counted: ready for the next launch
+      const uint32_t row0 = e_ty * TH, n_rows = AE->rows.n_rows;
+      const uint32_t rows_valid = n_rows - row0 < (uint32_t)TH ? n_rows - row0 : (uint32_t)TH;
+      const uint32_t x0 = t0 * TW;
+      const uint32_t cols = e_w - x0 < nt * TW ? e_w - x0 : nt * TW;  // pixels of the group inside the image
+      const size_t stile0 = (size_t)(e_ty * e_tiles_x + t0) * 64u;   // the group's first staging pixel
+      float *const h_depth = AE->host_depth, *const h_color = AE->host_color, *const h_normal = AE->host_normal;
+      // four rows at a time: 28 loads in flight, then their 28 stores (an atomic load is not moved across a
+      // store by the compiler, and a copy that waits for every load in turn would take ~100 us per group)
+      constexpr uint32_t RB = TH < 4 ? TH : 4;
+      for (uint32_t rb = 0; rb < rows_valid; rb += RB) {
+        float vd[RB], vc[RB][3], vn[RB][3];
+#pragma unroll
+        for (uint32_t q = 0; q < RB; q++) {
+          const uint32_t r = rb + q;
+          const bool row_ok = r < rows_valid;
+          vd[q] = 0.f;
+          if (row_ok && lane < cols)
+            vd[q] = __hip_atomic_load(depth_out + stile0 + (size_t)(lane / TW) * 64u + r * TW + lane % TW, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (uint32_t j = 0; j < 3; j++) {
+            const uint32_t f = j * 64u + lane, p = f / 3u;  // float f of the row's 3*cols, pixel p of the row
+            vc[q][j] = vn[q][j] = 0.f;
+            if (row_ok && p < cols) {
+              const size_t src = (stile0 + (size_t)(p / TW) * 64u + r * TW + p % TW) * 3u + f % 3u;
+              vc[q][j] = __hip_atomic_load(color_out + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              vn[q][j] = __hip_atomic_load(normal_out + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < RB; q++) {
+          const uint32_t r = rb + q;
+          if (r >= rows_valid) break;
+          const size_t dst_px = (size_t)(row0 + r) * e_w + x0;
+          if (lane < cols) h_depth[dst_px + lane] = vd[q];
+#pragma unroll
+          for (uint32_t j = 0; j < 3; j++) {
+            const uint32_t f = j * 64u + lane;
+            if (f / 3u < cols) {
+              h_color[dst_px * 3u + f] = vc[q][j];
+              h_normal[dst_px * 3u + f] = vn[q][j];
+            }
+          }
+        }
+      }
+    }
+  }
 
   if (A.cost && lane == 0) {
     const unsigned long long dt = (__builtin_readcyclecounter() - t_wave0) >> 6;
@@ -1280,11 +1374,88 @@ __device__ void fold_block(unsigned long long *__restrict__ shards, unsigned lon
   }
 }
 
+// The same counting sort (see order_block) over groups of GROUP_TILES horizontally adjacent tiles: a group's key is
+// the cost of its most expensive tile, its tiles are emitted consecutively.
+__device__ void order_block_groups(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n, uint32_t tiles_x) {
+  __shared__ uint32_t scan[CTR_COST_BINS];
+  __shared__ uint32_t wsum[CTR_COST_BINS / 64];
+  __shared__ uint32_t smax;
+  const uint32_t t = threadIdx.x, ln = t & 63u, wv = t >> 6;
+  const uint32_t groups_x = (tiles_x + GROUP_TILES - 1) / GROUP_TILES;
+  const uint32_t n_groups = (n / tiles_x) * groups_x;  // (single frame: n = tiles_x * tiles_y)
+  auto group = [&](uint32_t g, uint32_t &tile0, uint32_t &nt) -> uint32_t {  // -> the group's key
+    const uint32_t gy = g / groups_x, gx = g - gy * groups_x;
+    tile0 = gy * tiles_x + gx * GROUP_TILES;
+    nt = tiles_x - gx * GROUP_TILES < GROUP_TILES ? tiles_x - gx * GROUP_TILES : GROUP_TILES;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < nt; k++) c = cost[tile0 + k] > c ? cost[tile0 + k] : c;
+    return c;
+  };
+  scan[t] = 0u;
+  if (t == 0) smax = 1u;
+  __syncthreads();
+  uint32_t m = 0;
+  for (uint32_t g = t; g < n_groups; g += CTR_COST_BINS) {
+    uint32_t tile0, nt;
+    const uint32_t c = group(g, tile0, nt);
+    m = c > m ? c : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, off);
+    m = o > m ? o : m;
+  }
+  if (ln == 0) atomicMax(&smax, m);
+  __syncthreads();
+  const uint32_t top = __float_as_uint((float)smax);
+  auto bin = [&](uint32_t c, uint32_t i) -> uint32_t {
+    const uint32_t fb = __float_as_uint((float)c);
+    uint32_t cls = fb < top ? (top - fb) >> 20 : 0u;
+    cls = cls > 63u ? 63u : cls;
+    return cls * 16u + (i & 15u);
+  };
+  for (uint32_t g = t; g < n_groups; g += CTR_COST_BINS) {
+    uint32_t tile0, nt;
+    const uint32_t c = group(g, tile0, nt);
+    atomicAdd(&scan[bin(c, g)], nt);
+  }
+  __syncthreads();
+  const uint32_t v = scan[t];
+  uint32_t x = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)x, off);
+    if (ln >= (uint32_t)off) x += o;
+  }
+  if (ln == 63u) wsum[wv] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t q = 0; q < wv; q++) base += wsum[q];
+  scan[t] = base + x - v;
+  __syncthreads();
+  for (uint32_t g = t; g < n_groups; g += CTR_COST_BINS) {
+    uint32_t tile0, nt;
+    const uint32_t c = group(g, tile0, nt);
+    uint32_t at = atomicAdd(&scan[bin(c, g)], nt);
+    if (CTR_CHEAP_FIRST_PCT && tiles_x % GROUP_TILES == 0) {  // (every group is whole)
+      // the cheapest groups first, then the rest from the dearest down: the link to the host has something to carry
+      // from the start, while the dear tiles — which complete late whatever the order — are under way
+      const uint32_t tail = (uint32_t)((uint64_t)n_groups * CTR_CHEAP_FIRST_PCT / 100u) * GROUP_TILES;  // tiles moved to the front
+      at = at >= n - tail ? (n - nt - at) : at + tail;   // (the front in ascending cost)
+    }
+    for (uint32_t k = 0; k < nt; k++) order[at + k] = tile0 + k;
+  }
+}
+
 // block of CTR_COST_BINS threads: counting sort of the launch's waves by cost class, expensive first:
 // order[slot] = wave.  64 classes (8 per octave below the maximum) x 16 sub-bins by wave index —
 // the sub-bins only spread the LDS atomics of neighbouring waves, which usually share a class.
 // Any permutation is a correct order; cost only shapes the tail of the next launches.
-__device__ void order_block(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
+// tiles_x != 0: keep the GROUP_TILES tiles of a host-delivery group together (sorted by the group's cost), so that
+// a group completes — and its pixels leave for the host — soon after its first tile starts.
+__device__ void order_block(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n, uint32_t tiles_x) {
+  if (tiles_x) {
+    order_block_groups(cost, order, n, tiles_x);
+    return;
+  }
   __shared__ uint32_t scan[CTR_COST_BINS];
   __shared__ uint32_t wsum[CTR_COST_BINS / 64];
   __shared__ uint32_t smax;
@@ -1362,11 +1533,11 @@ static_assert(CTR_SHARDS == CTR_COST_BINS, "after_render uses one block size for
 __global__ __launch_bounds__(CTR_SHARDS) void after_render(unsigned long long *__restrict__ shards,
                                                            unsigned long long *__restrict__ counters,
                                                            const uint32_t *__restrict__ cost,
-                                                           uint32_t *__restrict__ order, uint32_t n) {
+                                                           uint32_t *__restrict__ order, uint32_t n, uint32_t group_tiles_x) {
   if (blockIdx.x == 0) {
     if (shards) fold_block(shards, counters);
   } else {
-    if (cost) order_block(cost, order, n);
+    if (cost) order_block(cost, order, n, group_tiles_x);
   }
 }
 
@@ -1410,6 +1581,13 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.frames = (uint32_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1);
   A.order = (const CADDR uint32_t *)L.order;
   A.cost = L.cost;
+  const bool host_delivery = (KV & KV_HOSTOUT) != 0;
+  if (host_delivery != (L.group_done != nullptr)) return (int)hipErrorInvalidValue;
+  if (host_delivery && (L.n_frames != 1 || !L.host_depth || !L.host_color || !L.host_normal)) return (int)hipErrorInvalidValue;
+  A.host_depth = L.host_depth;
+  A.host_color = L.host_color;
+  A.host_normal = L.host_normal;
+  A.group_done = L.group_done;
   size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
   // diagnostic only: extra dynamic LDS per workgroup caps the waves resident per CU (occupancy sweeps)
   if (const char *pad = getenv("CUTRACE_LDS_PAD")) lds_bytes += (size_t)atol(pad);
@@ -1424,7 +1602,8 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   const bool reorder = L.cost && L.order_next;
   if (shards || reorder)
     hipLaunchKernelGGL(after_render, dim3(reorder ? 2 : 1), dim3(CTR_SHARDS), 0, stream, shards, L.counters,
-                       reorder ? L.cost : nullptr, L.order_next, (uint32_t)waves);
+                       reorder ? L.cost : nullptr, L.order_next, (uint32_t)waves,
+                       host_delivery ? (L.w + TW - 1) / TW : 0u);
   return (int)hipGetLastError();
 }
 
@@ -1481,9 +1660,28 @@ extern "C" int ctr_selftest_exact_math(uint64_t *n_mismatch) {
 }
 
 uint64_t ctr_launch_waves(const RenderLaunch &L) { return launch_waves(L); }
+uint64_t ctr_staging_pixels(const RenderLaunch &L) { return launch_waves(L) * 64u; }
+uint64_t ctr_staging_groups(const RenderLaunch &L) {
+  const uint64_t tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.rows.n_rows + TH - 1) / TH;
+  return ((tiles_x + GROUP_TILES - 1) / GROUP_TILES) * tiles_y;
+}
+
+// Host delivery exists for the variants ctr_api.cpp picks by itself (not for the ablation / diagnostic builds)
+bool ctr_host_delivery_available(uint32_t variant) {
+  constexpr uint32_t DEF = KV_PREFILTER | KV_BVH | KV_FASTPOW;
+  return (variant & ~(KV_ANYHIT | KV_OCC6)) == DEF;
+}
 
 int ctr_launch_render(const RenderLaunch &L, void *stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (L.group_done) {
+    if (!ctr_host_delivery_available(L.variant)) return (int)hipErrorInvalidValue;
+    constexpr uint32_t DEF = KV_PREFILTER | KV_BVH | KV_FASTPOW | KV_HOSTOUT;
+    const size_t sb = (size_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1) * (L.need_cold_frames ? 10u : 4u) * 64 * sizeof(float);
+    if (!(L.variant & KV_ANYHIT)) return launch<DEF>(L, s);
+    if ((L.variant & KV_OCC6) && sb * 24 <= 160u * 1024u) return launch<DEF | KV_ANYHIT | KV_OCC6>(L, s);
+    return launch<DEF | KV_ANYHIT>(L, s);
+  }
   if (L.variant & KV_COUNT) return launch<KV_PREFILTER | KV_COUNT>(L, s);
   if (L.variant & KV_STATS)
     return (L.variant & KV_ANYHIT) ? launch<KV_BVH | KV_PREFILTER | KV_ANYHIT | KV_FASTPOW | KV_STATS>(L, s)

@@ -103,6 +103,7 @@ enum : uint32_t {
   KV_STATS = 16u,      // diagnostic: wave-level work counters into counters[4..9]
   KV_FASTPOW = 32u,    // specular pow() as exp2(e*log2(x)) in f32 instead of f64 pow
   KV_OCC6 = 64u,       // compiled for 6 waves per SIMD instead of 5 (large meshes: latency-bound on scalar-cache misses)
+  KV_HOSTOUT = 128u,   // the launch delivers the frame to page-locked host memory itself (RenderLaunch::group_done)
 };
 
 struct DRows {
@@ -151,7 +152,16 @@ struct RenderLaunch {
   uint32_t *cost;         // out: per-wave cost of this launch
   uint32_t *order_next;   // out (or null = keep the old order): waves sorted by descending cost
                           // (may alias `order`: written after the render)
+  // Host delivery (render_kernel.hip "Host delivery"; single frame only): when group_done is set, depth / color /
+  // normal above are a TILE-MAJOR staging area of ctr_staging_pixels() pixels each (x1, x3, x3 floats), and the
+  // frame is written into host_* — device-visible page-locked host memory, compact row-major as in ctr_render — by
+  // the wave that completes each group of tiles.  group_done: ctr_staging_groups() zeroed words (left zeroed).
+  float *host_depth, *host_color, *host_normal;
+  uint32_t *group_done;
 };
+uint64_t ctr_staging_pixels(const RenderLaunch &L);
+uint64_t ctr_staging_groups(const RenderLaunch &L);
+bool ctr_host_delivery_available(uint32_t kernel_variant);
 
 // keeps `msg` for ctr_last_error() (ctr_api.cpp); used by the other translation units of the library
 void ctr_internal_set_error(const char *msg);

@@ -240,6 +240,7 @@ int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
 #define CTR_VAR_EXACT_POW 32u     /* exact specular term: pow() in f64 (<=1 ulp of glibc powf), IEEE half-vector normalisation */
 #define CTR_VAR_STATS 16u         /* diagnostic build: print wave-level work counters to stderr */
 #define CTR_VAR_NO_REORDER 256u   /* always dispatch tiles in image order (see below) */
+#define CTR_VAR_NO_DIRECT 1024u   /* ctr_render: never let the kernel store into page-locked destinations itself (device buffers + DMA instead) */
 #define CTR_VAR_NO_OCC6 512u      /* never pick the build compiled for 6 waves per SIMD (chosen for scenes with >= 1000 mesh triangles) */
 /* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
  * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles

@@ -1,5 +1,5 @@
 """A/B timing of several builds of libcutrace_amd.so on the SAME box in one gpurun call (devices differ by
-several % — never compare numbers from different calls).  usage: gpu_ab.py name=path.so ... [--rounds N] [--stats]"""
+several % — never compare numbers from different calls).  usage: gpu_ab.py name=path.so ... [--rounds N] [--stats] [--host]"""
 import json, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -19,6 +19,9 @@ for name, path, b in todo:
     t = [ds.render(bounces=b)["kernel_ms"] for _ in range(9)]
     out[name] = round(statistics.median(t), 4)
     out[name + "_first"] = round(first, 4)
+    if "--host" in sys.argv:   # ctr_render into a page-locked block, whole call
+        for _ in range(3): ds.render(bounces=b, pinned=True)
+        out[name + "_host"] = round(statistics.median(ds.render(bounces=b, pinned=True)["total_ms"] for _ in range(9)), 4)
     if "--stats" in sys.argv:
         ds.set_variant(ca.VAR_STATS)
         ds.render(bounces=b)
@@ -26,7 +29,7 @@ print(json.dumps(out))
 ''' % ROOT
 libs = [a.split("=", 1) for a in sys.argv[1:] if "=" in a]
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 2
-extra = ["--stats"] if "--stats" in sys.argv else []
+extra = [f for f in ("--stats", "--host") if f in sys.argv]
 res = {n: [] for n, _ in libs}
 for r in range(rounds):
     for n, p in libs:

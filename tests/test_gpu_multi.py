@@ -152,3 +152,21 @@ def test_rccl_plumbing_self_send_recv(ca):
     assert _same(got, want)
     assert _same(m.render(bounces=5), want)
     m.close()
+
+
+@pytest.mark.parametrize("n_dev", [1, 2, 4])
+def test_page_locked_destination_is_written_by_the_device(ca, n_dev):
+    """A page-locked destination (ctr_frame_alloc) is written by device 0's kernels themselves — the render kernel
+    for one device, the re-interleave kernel for several — instead of a D2H copy afterwards: same bytes as with
+    CTR_VAR_NO_DIRECT and as into pageable memory, twice in a row (the block is reused)."""
+    s = load_scene(ca, "bunny", 480, 270)
+    want = ca.DeviceScene(s).render(bounces=4)
+    m = ca.MultiScene(s, [0] * n_dev)
+    for variant in (0, ca.VAR_NO_DIRECT, 0):
+        m.set_variant(variant)
+        got = m.render(bounces=4, pinned=True)
+        assert _same(got, want), (n_dev, variant)
+        got["depth"][:] = 0.0     # the next call must rewrite every pixel
+        got["color"][:] = 0.0
+        got["normal"][:] = 0.0
+    m.close()

@@ -485,12 +485,21 @@ def test_six_wave_build_and_pinned_frames_change_nothing(ca):
     ds.set_variant(ca.VAR_NO_OCC6)
     b = ds.render(bounces=5)
     ds.set_variant(0)
-    c = ds.render(bounces=5, pinned=True)
+    c = ds.render(bounces=5, pinned=True)              # the kernel stores into the page-locked block itself
     for k in ("depth", "normal", "color"):
         assert same_bits(a[k], b[k]), k
         assert same_bits(a[k], c[k]), k
     assert a["ray_count"] == b["ray_count"] == c["ray_count"] == 64278888
     assert a["max_depth"] == b["max_depth"] == c["max_depth"]
+    c["depth"][:] = 0.0
+    ds.set_variant(ca.VAR_NO_DIRECT)                   # device buffers + one DMA into the same block
+    c2 = ds.render(bounces=5, pinned=True)
+    ds.set_variant(0)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(a[k], c2[k]), k
+    c2["depth"][:] = 0.0
+    c3 = ds.render(bounces=5, pinned=True)             # and directly again, every pixel rewritten
+    assert same_bits(a["depth"], c3["depth"]) and same_bits(a["color"], c3["color"])
     # a row subset into the same (larger) pinned block, then the diagnostics
     d = ds.render(bounces=5, rows=(0, 1080, 8, 3, 8), pinned=True)
     ys = [y for y in range(1080) if (y // 8) % 8 == 3]
