@@ -114,17 +114,26 @@ def extras(ca, hs, args, ds):
     w, h = hs.size
     out = {}
     # (1) what the drop-in `cutrace <scene.json>` gets (main.cu:30: one frame per process): the FIRST launch of the
-    #     shape on a fresh scene handle, in image order, and the whole host-buffer call (kernel + one D2H of the
-    #     58 MB frame into page-locked memory = the reference's total_ms, kernel.hpp:88,126)
+    #     shape on a fresh scene handle, in image order — the kernel alone (device buffers), and the whole host-buffer
+    #     call into page-locked memory, which the kernel delivers itself while it renders (= the reference's
+    #     total_ms, kernel.hpp:88,126); then the same call in steady state, with the frame leaving by one DMA after
+    #     the kernel instead (CTR_VAR_NO_DIRECT), and through pageable memory
     fresh = ca.DeviceScene(hs, device=ds.device)
     fresh.render(bounces=args.bounces, rows=(0, 8), pinned=True)   # another shape: code object + clocks warm
-    r = fresh.render(bounces=args.bounces, pinned=True)
-    out["first_launch_kernel_ms"] = r["kernel_ms"]
-    out["first_launch_total_ms"] = r["total_ms"]
+    fresh.set_variant(ca.VAR_NO_DIRECT)
+    out["first_launch_kernel_ms"] = fresh.render(bounces=args.bounces, pinned=True)["kernel_ms"]
+    fresh.close()
+    fresh = ca.DeviceScene(hs, device=ds.device)
+    fresh.render(bounces=args.bounces, rows=(0, 8), pinned=True)
+    out["first_launch_total_ms"] = fresh.render(bounces=args.bounces, pinned=True)["total_ms"]
     for _ in range(3):
         fresh.render(bounces=args.bounces, pinned=True)
     rr = [fresh.render(bounces=args.bounces, pinned=True) for _ in range(5)]
     out["host_call_total_ms_pinned"] = statistics.median(x["total_ms"] for x in rr)
+    fresh.set_variant(ca.VAR_NO_DIRECT)
+    rr = [fresh.render(bounces=args.bounces, pinned=True) for _ in range(7)][2:]
+    out["host_call_total_ms_pinned_dma"] = statistics.median(x["total_ms"] for x in rr)
+    fresh.set_variant(0)
     out["host_call_total_ms_pageable"] = statistics.median(fresh.render(bounces=args.bounces)["total_ms"] for _ in range(3))
     # (2) how many of a wave's 64 lanes the wave-level work serves (CTR_VAR_STATS build of the same kernel)
     fresh.set_variant(ca.VAR_STATS)

@@ -163,11 +163,15 @@ int ctr_render(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
                float *depth, float *color3, float *normal3, ctr_render_stats *stats);
 
 /* Page-locked host memory for a frame's three buffers, as the consecutive parts of ONE block
- * [depth n | color 3n | normal 3n floats]: ctr_render then delivers the frame with a single direct DMA
- * queued behind the kernel (58 MB at 1080p: ~1.1 ms on PCIe 5) instead of three staged copies through
- * pageable memory.  Any page-locked destination (hipHostMalloc / hipHostRegister) gets the direct path,
- * one transfer per buffer.  Replaces the reference's cudaMallocManaged outputs + 3·h row copies
- * (inc/kernel.hpp:99-118).  Free with ctr_frame_free(depth). */
+ * [depth n | color 3n | normal 3n floats].  Page-locked destinations (this block, or any hipHostMalloc /
+ * mapped hipHostRegister memory, together or one by one) are visible to the device, and ctr_render then has
+ * the render kernel deliver the frame ITSELF: finished groups of tiles are copied into the host buffers while
+ * the rest of the frame is still being rendered, so the 28 bytes per pixel cross PCIe underneath the kernel
+ * instead of in a transfer after it (1920x1080 bunny: 1.44 ms per call against 2.15 ms for kernel + one DMA,
+ * 4.2 ms through pageable memory; first frame 1.66 against 2.6 ms).  Bits are the same on every path.
+ * CTR_VAR_NO_DIRECT falls back to device buffers + DMA (one transfer when the buffers are one block).
+ * Replaces the reference's cudaMallocManaged outputs + 3*h row copies (inc/kernel.hpp:99-118).
+ * Free with ctr_frame_free(depth). */
 int ctr_frame_alloc(uint64_t n_pixels, float **depth, float **color3, float **normal3);
 void ctr_frame_free(float *depth);
 
@@ -204,8 +208,9 @@ int ctr_render_device_batch(ctr_scene *scene, float fudge, int bounces, const ct
  * ONE process: the scene is replicated (ctr_multi_create uploads it to every listed device), device d
  * renders the interleaved row blocks {b : b mod N == d} of `block_rows` rows (0 = 8) into a compact buffer,
  * the N-1 compact buffers reach device 0 (= devices[0]) in ONE grouped RCCL send/recv over xGMI, a HIP
- * kernel re-interleaves them into the row-major frame, and one D2H delivers it to the caller's buffers
- * (same layout and semantics as ctr_render; page-locked destinations get direct DMA).  N = 1 needs no RCCL.
+ * kernel re-interleaves them into the row-major frame — straight into the caller's buffers when they are
+ * page-locked (whole rows, no D2H afterwards), else into a device frame that one D2H delivers (same layout and
+ * semantics as ctr_render).  N = 1 needs no RCCL and is ctr_render's own host delivery.
  * librccl.so is loaded on demand; a group that lists the same device more than once (rehearsal on a
  * one-GPU box), or a box without RCCL, moves the parts with hipMemcpyPeerAsync — ctr_multi_transport tells
  * which: "single", "rccl" or "peer-copy".  Results are bitwise those of ctr_render on one device.
@@ -240,7 +245,7 @@ int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
 #define CTR_VAR_EXACT_POW 32u     /* exact specular term: pow() in f64 (<=1 ulp of glibc powf), IEEE half-vector normalisation */
 #define CTR_VAR_STATS 16u         /* diagnostic build: print wave-level work counters to stderr */
 #define CTR_VAR_NO_REORDER 256u   /* always dispatch tiles in image order (see below) */
-#define CTR_VAR_NO_DIRECT 1024u   /* ctr_render: never let the kernel store into page-locked destinations itself (device buffers + DMA instead) */
+#define CTR_VAR_NO_DIRECT 1024u   /* ctr_render / ctr_render_multi: page-locked destinations get device buffers + DMA instead of delivery by the kernels */
 #define CTR_VAR_NO_OCC6 512u      /* never pick the build compiled for 6 waves per SIMD (chosen for scenes with >= 1000 mesh triangles) */
 /* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
  * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles
