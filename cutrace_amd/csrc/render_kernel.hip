@@ -1227,6 +1227,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   }
 #undef STK
 
+  // (the tile's cost for the next launch's order ends here: what the group copy below costs the one wave that makes
+  //  it depends on the link, not on the tile)
+  const unsigned long long t_wave1 = HOSTOUT ? __builtin_readcyclecounter() : 0ull;
   if (HOSTOUT) {
     const CADDR KArgs *AE = (const CADDR KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(AE));  // the kernel arguments once more (see AK): none of this is worth an SGPR across the loop
@@ -1295,7 +1298,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   }
 
   if (A.cost && lane == 0) {
-    const unsigned long long dt = (__builtin_readcyclecounter() - t_wave0) >> 6;
+    const unsigned long long dt = ((HOSTOUT ? t_wave1 : __builtin_readcyclecounter()) - t_wave0) >> 6;
     const uint32_t c = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
     A.cost[wave] = c;
   }
