@@ -943,7 +943,8 @@ int ctr_tile_costs(ctr_scene *s, uint32_t *out, uint64_t capacity, uint64_t *n_t
 int ctr_frame_alloc(uint64_t n_pixels, float **depth, float **color3, float **normal3) {
   if (!depth || !color3 || !normal3 || n_pixels == 0) return fail(CTR_E_INVALID, "ctr_frame_alloc: bad argument");
   float *p = nullptr;
-  HIP_TRY(hipHostMalloc((void **)&p, sizeof(float) * 7 * n_pixels, hipHostMallocDefault));
+  // portable + mapped: page-locked for, and visible to, every device of the process (whichever one is current now)
+  HIP_TRY(hipHostMalloc((void **)&p, sizeof(float) * 7 * n_pixels, hipHostMallocPortable | hipHostMallocMapped));
   *depth = p;
   *color3 = p + n_pixels;
   *normal3 = p + 4 * n_pixels;
