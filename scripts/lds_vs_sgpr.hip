@@ -13,6 +13,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/bin/lds_vs_sgpr scripts/lds_vs_sgpr.hip && scripts/bin/lds_vs_sgpr
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
@@ -53,6 +54,22 @@ __global__ __launch_bounds__(256) void via_sgpr(const float *__restrict__ recs, 
 #pragma unroll
     for (int j = 0; j < REC; j++) v[j] = r[j];
     acc = work<PACKED>(v, x, acc);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// the scalar path again, every wave walking its own pseudo-random sequence of records (a BVH walk is not a stream):
+// no two waves ask for the same line at the same time, so nothing merges on the way to L2
+__global__ __launch_bounds__(256) void via_sgpr_scattered(const float *__restrict__ recs, int n_rec, int steps, float *out, float x) {
+  float acc = (float)threadIdx.x;
+  uint32_t i = __builtin_amdgcn_readfirstlane((blockIdx.x * 4u + (threadIdx.x >> 6)) * 2654435761u);
+  for (int s = 0; s < steps; s++) {
+    i = i * 1664525u + 1013904223u;  // (scalar ALU)
+    const float *r = recs + (size_t)((i >> 8) & (uint32_t)(n_rec - 1)) * REC;  // (n_rec: a power of two)
+    float v[REC];
+#pragma unroll
+    for (int j = 0; j < REC; j++) v[j] = r[j];
+    acc = work<true>(v, x, acc);
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
@@ -126,6 +143,30 @@ int main() {
       const double ns_s = ms[0] * 1e6 / ((double)k * n_rec), ns_l = ms[1] * 1e6 / ((double)k * n_rec);
       printf("%-16d %10.2f %10.2f %8.2f\n", k, ns_s, ns_l, ns_l / ns_s);
     }
+  }
+  printf("scalar path, every wave its own random sequence of records, 8 v_pk_fma_f32 per record; by working set\n");
+  printf("%-16s %12s %12s %12s %12s\n", "waves per SIMD", "8 KB", "64 KB", "1 MB", "4 MB");
+  float *big;
+  CK(hipMalloc((void **)&big, (size_t)65536 * REC * sizeof(float)));
+  CK(hipMemset(big, 0, (size_t)65536 * REC * sizeof(float)));
+  for (int k : {1, 2, 4, 6, 8}) {
+    printf("%-16d", k);
+    for (int set : {128, 1024, 16384, 65536}) {
+      const int steps = 16384, blocks = n_cu * k;
+      std::vector<float> t;
+      for (int rep = 0; rep < 7; rep++) {
+        CK(hipEventRecord(e0, nullptr));
+        via_sgpr_scattered<<<blocks, 256>>>(big, set, steps, out, 1.0001f);
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float x;
+        CK(hipEventElapsedTime(&x, e0, e1));
+        if (rep >= 2) t.push_back(x);
+      }
+      std::sort(t.begin(), t.end());
+      printf(" %12.2f", t[t.size() / 2] * 1e6 / ((double)k * steps));
+    }
+    printf("\n");
   }
   return 0;
 }
