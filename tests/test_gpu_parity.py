@@ -511,3 +511,30 @@ def test_six_wave_build_and_pinned_frames_change_nothing(ca):
     cnt = ds.last_counters()
     assert int(cnt[0]) == 64278888 and int(cnt[4]) == 972000     # 30 trips for each of the 32 400 waves
     assert 0 < int(cnt[10]) <= 64 * int(cnt[5]) and 0 < int(cnt[11]) <= 64 * int(cnt[6]) and 0 < int(cnt[12]) <= 64 * int(cnt[7])
+
+
+def test_host_delivery_with_changing_frames(ca):
+    """Delivery into page-locked memory by the kernel stages every tile in device memory and copies it to the host from
+    another wave, usually on another XCD (render_kernel.hip "Host delivery").  Frames of DIFFERENT content through the
+    same scene handle — a moving camera, changing bounce counts, full size — so that a pixel left over from the previous
+    frame (a stale cache line, a group copied before its last tile arrived) cannot go unnoticed: every frame bitwise
+    equal to the same frame through device buffers + DMA on a second handle."""
+    import ctypes as C
+    from cutrace_amd import _lib
+    s = load_scene(ca, "bunny")
+    cam0 = s.desc.contents.cam
+    direct, plain = ca.DeviceScene(s), ca.DeviceScene(s)
+    plain.set_variant(ca.VAR_NO_DIRECT)
+    for i in range(6):
+        c = ca.Camera()
+        C.memmove(C.byref(c), C.byref(cam0), C.sizeof(ca.Camera))
+        _lib.host_lib().ctr_camera_look_at(C.byref(c), _lib.Vec3(1.0 - 0.1 * i, 0.05 * i, 2.0 - 0.03 * i), _lib.Vec3(0, 1, 0),
+                                           _lib.Vec3(-0.92388 + 0.02 * i, 0.0, -0.38268))
+        direct.set_cameras([c])
+        plain.set_cameras([c])
+        b = (5, 1, 3, 0, 5, 2)[i]
+        got = direct.render(bounces=b, pinned=True)
+        want = plain.render(bounces=b, pinned=True)
+        for k in ("depth", "normal", "color"):
+            assert same_bits(got[k], want[k]), (i, k)
+        assert got["ray_count"] == want["ray_count"] and got["max_depth"] == want["max_depth"]
