@@ -49,6 +49,9 @@ def parse_args():
     p.add_argument("--height", type=int, default=0)
     p.add_argument("--bounces", type=int, default=5)
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    p.add_argument("--roots", choices=["rotate", "rank0"], default="rotate",
+                   help="which rank a frame is gathered to when a step has several frames: frame f -> rank f mod N "
+                        "(balanced xGMI links and re-interleave work), or always rank 0")
     p.add_argument("--variant", type=int, default=0)
     p.add_argument("--skip-probe", action="store_true",
                    help="skip the untimed image-order launches after the timed region (profiling runs)")
@@ -208,12 +211,12 @@ def main():
     sim = args.of if (world == 1 and args.of > 1) else 0
     if sim:  # one process plays rank `as_rank` of `of` ranks: same launches, no collective
         frames = sim if args.scaling == "weak" else 1
-        tiler = FrameTiler(w, h, frames, args.as_rank, sim, dev)
+        tiler = FrameTiler(w, h, frames, args.as_rank, sim, dev, roots=args.roots)
         tiler.gather = lambda slot: None
         tiler.begin = lambda slot: None
         tiler.finish = lambda: None
     else:
-        tiler = FrameTiler(w, h, frames, rank, world, dev)
+        tiler = FrameTiler(w, h, frames, rank, world, dev, roots=args.roots)
     if frames > 1:
         import ctypes
         cam0 = hs.desc.contents.cam
@@ -291,16 +294,23 @@ def main():
     else:
         dt_max, rays_step, kern_avg = dt, float(rays_rank_step), float(t[2])
 
-    if args.check and rank == 0:
+    if args.check and not sim:
         import numpy as np
-        ref = ca.DeviceScene(hs, device=local_rank)
-        ref.set_variant(ca.VAR_NO_REORDER)
-        want = ref.render(bounces=args.bounces)
-        for f in range(frames):
-            for k in ("depth", "color", "normal"):
-                got = tiler.final[k][f].cpu().numpy()
-                assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), f"--check: frame {f} {k} differs"
-        print(f"check: {frames} gathered frame(s) bitwise equal to the single-process render", file=sys.stderr, flush=True)
+        n_ok = torch.zeros(1, dtype=torch.int64, device=dev)
+        if tiler.final_frames:  # every root rank checks the frames it assembled
+            ref = ca.DeviceScene(hs, device=local_rank)
+            ref.set_variant(ca.VAR_NO_REORDER)
+            want = ref.render(bounces=args.bounces)
+            for i, f in enumerate(tiler.final_frames):
+                for k in ("depth", "color", "normal"):
+                    got = tiler.final[k][i].cpu().numpy()
+                    assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), f"--check: rank {rank} frame {f} {k} differs"
+                n_ok += 1
+        if world > 1:
+            dist.all_reduce(n_ok)
+        assert int(n_ok.item()) == frames, f"--check: {int(n_ok.item())} of {frames} frames were assembled"
+        if rank == 0:
+            print(f"check: {frames} gathered frame(s) bitwise equal to the single-process render", file=sys.stderr, flush=True)
 
     if rank == 0:
         total_rays = rays_step * args.steps
@@ -346,7 +356,8 @@ def main():
                 "source": "profiles/r02/counters.json (rocprofv3 --pmc passes of this command), profiles/r02/valu_mix.json, "
                           "profiles/r02/valu_issue.txt"})
         config = {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
-                              f"{frames} frame(s)/step row-tiled over {world} GPU(s), gather to rank 0",
+                              f"{frames} frame(s)/step row-tiled over {world} GPU(s), "
+                              + ("frame f gathered to rank f mod N" if tiler.rotate_roots else "gather to rank 0"),
                   "tile_order": "expensive tiles first, costs recorded by the previous launch of the same "
                                 "shape (first launch of a shape: image order)",
                   "kernel_ms_image_order": kern_io,

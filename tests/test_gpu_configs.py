@@ -147,11 +147,13 @@ def test_cli_drop_in(ca, tmp_path):
     assert p.returncode == 254 and "Type 'model' is invalid." in p.stderr
 
 
-def test_bench_multi_rank_path_on_one_gpu(ca):
-    """bench.py's N>1 path end to end ON THE DEVICE: two ranks share GPU 0 and gloo stands in for RCCL
-    (which refuses two ranks on one GPU); rank 0 checks every gathered frame bitwise against a
-    single-process render (--check).  Exercises the batched launch with rotating row parts, the async
-    gather, the side-stream re-interleave and the double buffering with device tensors."""
+@pytest.mark.parametrize("ranks,roots", [(2, "rotate"), (3, "rotate"), (2, "rank0")])
+def test_bench_multi_rank_path_on_one_gpu(ca, ranks, roots):
+    """bench.py's N>1 path end to end ON THE DEVICE: the ranks share GPU 0 and gloo stands in for RCCL
+    (which refuses two ranks on one GPU); every root rank checks the frames gathered to it bitwise against a
+    single-process render (--check).  Exercises the batched launch with rotating row parts, the async grouped
+    send/recv exchange (frame f to rank f mod N, or all to rank 0), the side-stream re-interleave and the double
+    buffering with device tensors."""
     import socket
     import subprocess
     import sys
@@ -160,9 +162,9 @@ def test_bench_multi_rank_path_on_one_gpu(ca):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, CUTRACE_BENCH_SHARE_GPU="1", CUTRACE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--width", "480", "--height", "272", "--check"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
+           "--width", "480", "--height", "272", "--check", "--roots", roots]
     import signal
     p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                          start_new_session=True)  # own process group: a hang must not leave ranks behind
@@ -173,11 +175,12 @@ def test_bench_multi_rank_path_on_one_gpu(ca):
         p.communicate()
         raise AssertionError("multi-rank rehearsal timed out")
     assert p.returncode == 0, err_s[-2000:]
-    assert "check: 2 gathered frame(s) bitwise equal" in err_s
+    assert f"check: {ranks} gathered frame(s) bitwise equal" in err_s
     line = [l for l in out_s.splitlines() if l.startswith("{")][-1]
     import json
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["frames_per_step"] == 2
+    assert out["n_gpus"] == ranks and out["scaling"] == "weak" and out["config"]["frames_per_step"] == ranks
+    assert ("rank f mod N" in out["config"]["workload"]) == (roots == "rotate")
 
 
 ALL_OFF = None

@@ -1,6 +1,6 @@
 """The N>1 path on CPU: world_size-2 (and 3) gloo runs of the row tiling + gather + re-interleave
 (cutrace_amd/tiling.py), with the oracle standing in for the renderer (tests are the only place
-the oracle may be used).  The gathered frames on rank 0 must equal the single-process frame."""
+the oracle may be used).  The gathered frames on their root ranks must equal the single-process frames."""
 import os
 import socket
 import sys
@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, frames, steps, out_path):
+def _worker(rank, world, port, w, h, frames, steps, roots, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,13 +33,14 @@ def _worker(rank, world, port, w, h, frames, steps, out_path):
     from cutrace_amd.tiling import FrameTiler
     s = ca.HostScene.load("scene/sphere_plane.json")
     s.set_size(w, h)
-    tiler = FrameTiler(w, h, frames, rank, world, "cpu")
+    tiler = FrameTiler(w, h, frames, rank, world, "cpu", roots=roots)
     total_rays = 0
     for step in range(steps):
         slot = step % tiler.slots
         tiler.begin(slot)
         for f in range(frames):
-            r = oracle.oracle_render(s, bounces=2 + f, rows=tiler.frame_rows(f), threads=2)  # frames differ by bounces
+            # frames differ by bounces, steps by fudge: a piece left over from another frame or step would show
+            r = oracle.oracle_render(s, bounces=2 + f, fudge=1e-3 * (1 + step), rows=tiler.frame_rows(f), threads=2)
             d, c, n = tiler.views(slot, f)
             d.copy_(torch.from_numpy(r["depth"]).reshape(-1))
             c.copy_(torch.from_numpy(r["color"]).reshape(-1))
@@ -49,29 +50,43 @@ def _worker(rank, world, port, w, h, frames, steps, out_path):
     tiler.finish()
     t = torch.tensor([total_rays], dtype=torch.int64)
     dist.all_reduce(t)
-    if rank == 0:
-        np.savez(out_path, depth=tiler.final["depth"].numpy(), color=tiler.final["color"].numpy(),
+    if tiler.final_frames:  # every root saves the frames it assembled (last step)
+        np.savez(os.path.join(out_dir, f"final_rank{rank}.npz"), frames=np.array(tiler.final_frames),
+                 depth=tiler.final["depth"].numpy(), color=tiler.final["color"].numpy(),
                  normal=tiler.final["normal"].numpy(), rays=int(t[0]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h", [(2, 40), (3, 37)])
-def test_gather_reassembles_frames(ca, tmp_path, world, h):
-    w, frames, steps = 48, 2, 3
-    out = str(tmp_path / "final.npz")
-    mp.spawn(_worker, args=(world, _free_port(), w, h, frames, steps, out), nprocs=world, join=True)
-    got = np.load(out)
+@pytest.mark.parametrize("world,h,frames,roots", [(2, 40, 2, "rotate"), (3, 37, 3, "rotate"), (2, 40, 3, "rotate"),
+                                                    (3, 37, 2, "rank0"), (2, 24, 1, "rotate")])
+def test_gather_reassembles_frames(ca, tmp_path, world, h, frames, roots):
+    """Every frame of a step reaches ONE rank whole: rank f % world with rotating roots (a step of several frames),
+    rank 0 otherwise — bitwise the single-process frame, and every frame exactly once."""
+    w, steps = 48, 3
+    mp.spawn(_worker, args=(world, _free_port(), w, h, frames, steps, roots, str(tmp_path)), nprocs=world, join=True)
     s = ca.HostScene.load("scene/sphere_plane.json")
     s.set_size(w, h)
-    rays = 0
-    for f in range(frames):
-        full = oracle.oracle_render(s, bounces=2 + f, threads=4)
-        rays += full["ray_count"]
-        assert np.array_equal(got["depth"][f].view(np.uint32), full["depth"].view(np.uint32))
-        assert np.array_equal(got["color"][f].view(np.uint32), full["color"].view(np.uint32))
-        assert np.array_equal(got["normal"][f].view(np.uint32), full["normal"].view(np.uint32))
-    assert int(got["rays"]) == rays * steps
+    seen, rays, total = {}, 0, None
+    for rank in range(world):
+        path = tmp_path / f"final_rank{rank}.npz"
+        if not path.exists():
+            continue
+        got = np.load(path)
+        total = int(got["rays"])
+        for i, f in enumerate(got["frames"]):
+            assert int(f) not in seen
+            seen[int(f)] = rank
+            full = oracle.oracle_render(s, bounces=2 + int(f), fudge=1e-3 * steps, threads=4)
+            assert np.array_equal(got["depth"][i].view(np.uint32), full["depth"].view(np.uint32)), (rank, f)
+            assert np.array_equal(got["color"][i].view(np.uint32), full["color"].view(np.uint32)), (rank, f)
+            assert np.array_equal(got["normal"][i].view(np.uint32), full["normal"].view(np.uint32)), (rank, f)
+    rotating = roots == "rotate" and frames > 1
+    assert seen == {f: (f % world if rotating else 0) for f in range(frames)}
+    for step in range(steps):
+        for f in range(frames):
+            rays += oracle.oracle_render(s, bounces=2 + f, fudge=1e-3 * (1 + step), threads=4)["ray_count"]
+    assert total == rays
 
 
 def test_partition_covers_every_row_once():
