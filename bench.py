@@ -136,8 +136,14 @@ def extras(ca, hs, args, ds):
     fresh.set_variant(ca.VAR_NO_DIRECT)
     rr = [fresh.render(bounces=args.bounces, pinned=True) for _ in range(7)][2:]
     out["host_call_total_ms_pinned_dma"] = statistics.median(x["total_ms"] for x in rr)
+    # ordinary (pageable) buffers: three hipMemcpy after the kernel — into buffers reused from call to call, and into
+    # freshly allocated ones (numpy.empty per call: every destination page is touched for the first time by the copy)
     fresh.set_variant(0)
-    out["host_call_total_ms_pageable"] = statistics.median(fresh.render(bounces=args.bounces)["total_ms"] for _ in range(3))
+    bufs = fresh.render(bounces=args.bounces)
+    for _ in range(3):
+        fresh.render(bounces=args.bounces, into=bufs)
+    out["host_call_total_ms_pageable"] = statistics.median(fresh.render(bounces=args.bounces, into=bufs)["total_ms"] for _ in range(5))
+    out["host_call_total_ms_pageable_fresh_buffers"] = statistics.median(fresh.render(bounces=args.bounces)["total_ms"] for _ in range(3))
     # (2) how many of a wave's 64 lanes the wave-level work serves (CTR_VAR_STATS build of the same kernel)
     fresh.set_variant(ca.VAR_STATS)
     fresh.render(bounces=args.bounces)

@@ -158,13 +158,17 @@ class DeviceScene:
             _lib.hip_lib().ctr_frame_free(self._pin)
             self._pin_px = 0
 
-    def render(self, fudge=1e-3, bounces=5, rows=None, pinned=False):
+    def render(self, fudge=1e-3, bounces=5, rows=None, pinned=False, into=None):
         """Host-buffer form (ctr_render): returns numpy buffers + stats.  pinned=True: the buffers are views of
-        the scene handle's page-locked frame block (valid until the next pinned render / close)."""
+        the scene handle's page-locked frame block (valid until the next pinned render / close).  into: a dict
+        returned by an earlier call of the same shape, whose buffers are written again."""
         L = _lib.hip_lib()
         r = make_rows(self.h, rows)
         n = rows_count(self.h, rows)
-        if pinned:
+        if into is not None:
+            depth, color, normal = into["depth"], into["color"], into["normal"]
+            assert depth.shape == (n, self.w) and color.shape == (n, self.w, 3) and normal.shape == (n, self.w, 3)
+        elif pinned:
             px = max(n * self.w, 1)
             blk = self._pinned_frame(px)
             depth = blk[:px].reshape(n, self.w) if n else np.empty((0, self.w), np.float32)

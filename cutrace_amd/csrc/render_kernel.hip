@@ -1283,13 +1283,15 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           const uint32_t r = rb + q;
           if (r >= rows_valid) break;
           const size_t dst_px = (size_t)(row0 + r) * e_w + x0;
-          if (lane < cols) h_depth[dst_px + lane] = vd[q];
+          // written through to the host (system scope): 2-7 % faster per call than plain stores, which leave it to the
+          // L2 when the lines go out (the host buffers may be cached there like any other memory)
+          if (lane < cols) __hip_atomic_store(h_depth + dst_px + lane, vd[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
           for (uint32_t j = 0; j < 3; j++) {
             const uint32_t f = j * 64u + lane;
             if (f / 3u < cols) {
-              h_color[dst_px * 3u + f] = vc[q][j];
-              h_normal[dst_px * 3u + f] = vn[q][j];
+              __hip_atomic_store(h_color + dst_px * 3u + f, vc[q][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(h_normal + dst_px * 3u + f, vn[q][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
           }
         }

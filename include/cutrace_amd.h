@@ -167,8 +167,10 @@ int ctr_render(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows,
  * mapped hipHostRegister memory, together or one by one) are visible to the device, and ctr_render then has
  * the render kernel deliver the frame ITSELF: finished groups of tiles are copied into the host buffers while
  * the rest of the frame is still being rendered, so the 28 bytes per pixel cross PCIe underneath the kernel
- * instead of in a transfer after it (1920x1080 bunny: 1.44 ms per call against 2.15 ms for kernel + one DMA,
- * 4.2 ms through pageable memory; first frame 1.66 against 2.6 ms).  Bits are the same on every path.
+ * instead of in a transfer after it (1920x1080 bunny: 1.4 ms per call against 2.15 ms for kernel + one DMA;
+ * first frame 1.66 against 2.6 ms).  Ordinary (pageable) destinations get three hipMemcpy after the kernel: 2.2 ms
+ * per call into buffers that are reused, 4-5 ms when the copy is the first to touch the destination's pages.
+ * Bits are the same on every path.
  * CTR_VAR_NO_DIRECT falls back to device buffers + DMA (one transfer when the buffers are one block).
  * Replaces the reference's cudaMallocManaged outputs + 3*h row copies (inc/kernel.hpp:99-118).
  * Free with ctr_frame_free(depth). */

@@ -26,8 +26,21 @@ for name, path, b in todo:
     for _ in range(4):
         ds.render(bounces=b)
     steady = statistics.median(ds.render(bounces=b)["kernel_ms"] for _ in range(7))
-    tot_pageable = statistics.median(ds.render(bounces=b)["total_ms"] for _ in range(5))
-    ds.render(bounces=b, pinned=True)
+    # whole host-buffer calls: pageable buffers (reused from call to call / fresh ones), page-locked with the frame by one
+    # DMA after the kernel (CTR_VAR_NO_DIRECT), page-locked with the frame delivered by the kernel
+    bufs = ds.render(bounces=b)
+    for _ in range(3):
+        ds.render(bounces=b, into=bufs)
+    tot_pageable = statistics.median(ds.render(bounces=b, into=bufs)["total_ms"] for _ in range(5))
+    tot_fresh = statistics.median(ds.render(bounces=b)["total_ms"] for _ in range(3))
+    ds.set_variant(ca.VAR_NO_DIRECT)
+    for _ in range(3):
+        ds.render(bounces=b, pinned=True)
+    tot_dma = statistics.median(ds.render(bounces=b, pinned=True)["total_ms"] for _ in range(5))
+    ds.set_variant(0)
+    for _ in range(4):
+        ds.render(bounces=b, pinned=True)
     tot_pinned = statistics.median(ds.render(bounces=b, pinned=True)["total_ms"] for _ in range(5))
     print(f"{name:13s} first launch (image order) {res['image']:.3f} ms, new shape on warm buffers {min(warm['image']):.3f} ms; steady {steady:.3f} ms "
-          f"(first/steady = {res['image'] / steady:.3f}); ctr_render total_ms: pageable {tot_pageable:.2f}, page-locked {tot_pinned:.2f}", flush=True)
+          f"(first/steady = {res['image'] / steady:.3f}); ctr_render total_ms: pageable {tot_pageable:.2f} (fresh buffers per call {tot_fresh:.2f}), "
+          f"page-locked by DMA {tot_dma:.2f}, page-locked delivered by the kernel {tot_pinned:.2f}", flush=True)

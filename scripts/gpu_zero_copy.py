@@ -30,3 +30,11 @@ for name, var in (("device buffers + one DMA", ca.VAR_NO_DIRECT), ("kernel store
     ds.close()
 a, b = res.values()
 print("bytes equal:", all(np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)) for k in a))
+# ordinary (pageable) destinations: three hipMemcpy after the kernel, into reused and into fresh buffers
+ds = ca.DeviceScene(s)
+bufs = ds.render(bounces=bounces)
+rr = [ds.render(bounces=bounces, into=bufs) for _ in range(12)][4:]
+fr = [ds.render(bounces=bounces) for _ in range(6)][2:]
+print(f"pageable, hipMemcpy       : buffers reused: steady total {statistics.median(x['total_ms'] for x in rr):.3f} ms; fresh numpy buffers per call: "
+      f"{statistics.median(x['total_ms'] for x in fr):.3f} ms (kernel {statistics.median(x['kernel_ms'] for x in rr):.3f})", flush=True)
+ds.close()
