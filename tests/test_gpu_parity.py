@@ -538,3 +538,37 @@ def test_host_delivery_with_changing_frames(ca):
         for k in ("depth", "normal", "color"):
             assert same_bits(got[k], want[k]), (i, k)
         assert got["ray_count"] == want["ray_count"] and got["max_depth"] == want["max_depth"]
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (9, 9), (65, 7), (64, 8), (63, 129), (200, 3), (513, 70)])
+def test_host_delivery_odd_sizes_and_separate_buffers(ca, w, h):
+    """Delivery by the kernel at sizes with ragged tiles, ragged tile groups and fewer rows than a tile, into ONE
+    page-locked block and into three separately page-locked buffers (torch pinned tensors, in a different order in memory),
+    with whole-frame and interleaved-part row selections: bitwise the frame through pageable buffers."""
+    import ctypes as C
+    import torch
+    from cutrace_amd import _lib
+    s = load_scene(ca, "bunny", w, h)
+    ds = ca.DeviceScene(s)
+    want = ds.render(bounces=3)
+    got = ds.render(bounces=3, pinned=True)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(got[k], want[k]), k
+    assert got["ray_count"] == want["ray_count"] and got["max_depth"] == want["max_depth"]
+    L = _lib.hip_lib()
+    for rows in (None, (0, h, 8, 1, 2)):
+        ref = ds.render(bounces=3, rows=rows)
+        n = ref["depth"].shape[0]
+        if n == 0:
+            continue
+        normal = torch.zeros(n * w * 3, dtype=torch.float32).pin_memory()   # allocated first: not in [depth|color|normal] order
+        depth = torch.zeros(n * w, dtype=torch.float32).pin_memory()
+        color = torch.zeros(n * w * 3, dtype=torch.float32).pin_memory()
+        r = ca.make_rows(h, rows)
+        stats = ca.RenderStats()
+        assert L.ctr_render(ds._h, C.c_float(1e-3), 3, C.byref(r), depth.data_ptr(), color.data_ptr(), normal.data_ptr(),
+                            C.byref(stats)) == 0
+        assert same_bits(depth.numpy().reshape(n, w), ref["depth"])
+        assert same_bits(color.numpy().reshape(n, w, 3), ref["color"])
+        assert same_bits(normal.numpy().reshape(n, w, 3), ref["normal"])
+        assert int(stats.ray_count) == ref["ray_count"]
