@@ -897,9 +897,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             const CADDR DNode4 *nodes4 = A.nodes4 + O.node_begin;
             // direction signs of the first lane that needs the mesh decide the visiting order (speed only)
             const uint32_t lead = (uint32_t)__builtin_ctzll(bb_m);
-            const uint32_t neg_bits = (__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31) |
-                                      ((__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31) << 1) |
-                                      ((__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31) << 2);
+            // (readlane returns int: shift its bits as unsigned — only bits 0..2 are used below, but an arithmetic shift
+            //  would smear the sign over the whole word)
+            const uint32_t neg_bits = ((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31) |
+                                      (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31) << 1) |
+                                      (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31) << 2);
             // the nine per-ray constants of the box test, two to a register pair; PKFMA picks the half it
             // needs with op_sel, so packing costs no extra registers
             const float2_ c_rxy = {ria.x, ria.y}, c_rzk = {ria.z, ka.x}, c_kyz = {ka.y, ka.z};
