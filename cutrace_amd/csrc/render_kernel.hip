@@ -899,9 +899,17 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             const uint32_t lead = (uint32_t)__builtin_ctzll(bb_m);
             // (readlane returns int: shift its bits as unsigned — only bits 0..2 are used below, but an arithmetic shift
             //  would smear the sign over the whole word)
-            const uint32_t neg_bits = ((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31) |
-                                      (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31) << 1) |
-                                      (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31) << 2);
+            const uint32_t nb_x = (uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.x), lead) >> 31,
+                           nb_y = (uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.y), lead) >> 31,
+                           nb_z = (uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.z), lead) >> 31;
+            // Visiting order (speed only; any order gives the same hit).  Nearest-hit casts go near to far along the lead
+            // ray — what they find prunes the rest.  Shadow casts go FAR to near: they start on a surface, whose own
+            // neighbourhood is what a near-to-far walk would test first and what occludes least (bunny -2 %, the
+            // 64 000-triangle mesh -8 % against near-to-far for both; profiles/r02/traversal_order.txt).
+            // (only where a shadow cast stops at its first occluder; the ordered shadow loop of scenes with transparent
+            //  materials is a nearest-hit cast)
+            const uint32_t lead_shadow = (ANYHIT && (uint32_t)__builtin_amdgcn_readlane(mode, lead) == (uint32_t)M_SHADOW) ? 7u : 0u;
+            const uint32_t neg_bits = lead_shadow ^ (nb_x | (nb_y << 1) | (nb_z << 2));
             // the nine per-ray constants of the box test, two to a register pair; PKFMA picks the half it
             // needs with op_sel, so packing costs no extra registers
             const float2_ c_rxy = {ria.x, ria.y}, c_rzk = {ria.z, ka.x}, c_kyz = {ka.y, ka.z};
