@@ -622,6 +622,12 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           const float mw = fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f;
           const V3 t_ka = mk((ro.x + mw) * ria.x, (ro.y + mw) * ria.y, (ro.z + mw) * ria.z);
           const V3 t_kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);
+          const uint32_t t_lead = (uint32_t)__builtin_ctzll(lv_m);
+          const uint32_t t_neg =
+              (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.x), t_lead) >> 31) |
+               (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.y), t_lead) >> 31) << 1) |
+               (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.z), t_lead) >> 31) << 2)) ^
+              ((ANYHIT && (uint32_t)__builtin_amdgcn_readlane(mode, t_lead) == (uint32_t)M_SHADOW) ? 7u : 0u);
           while (t_pend != TL_NONE && !(t_pend & BVH_LEAF_FLAG)) {
             const CADDR DNode &N = A.nodes[AK->tlas_begin + t_pend];
             auto t_hits = [&](int c) -> mask_t {
@@ -632,8 +638,12 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
               return lv_m & ~(FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, t_lim, FC_OGT));
             };
-            const bool hl = t_hits(0) != 0ull, hr = t_hits(1) != 0ull;
-            const uint32_t dl = N.left, dr = N.right;
+            // visiting order as in the per-mesh walk (speed only): along the lead ray for nearest-hit casts, against
+            // it for any-hit shadow casts
+            const bool t_rev = ((t_neg >> N.axis) & 1u) != 0u;
+            const bool h0 = t_hits(0) != 0ull, h1 = t_hits(1) != 0ull;
+            const bool hl = t_rev ? h1 : h0, hr = t_rev ? h0 : h1;
+            const uint32_t dl = t_rev ? N.right : N.left, dr = t_rev ? N.left : N.right;
             if (hl && hr) {
               t_stack_v = ctr_writelane(__builtin_amdgcn_readfirstlane(dr),
                                                        __builtin_amdgcn_readfirstlane(t_sp), t_stack_v);
