@@ -24,6 +24,7 @@ VAR_EXACT_POW = 32
 VAR_NO_REORDER = 256
 VAR_NO_OCC6 = 512
 VAR_NO_DIRECT = 1024
+VAR_IMAGE_ORDER_FIRST = 2048
 
 
 @contextlib.contextmanager

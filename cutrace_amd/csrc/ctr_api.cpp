@@ -55,6 +55,9 @@ inline f3 cross(f3 a, f3 o) { return {a.y * o.z - a.z * o.y, a.z * o.x - a.x * o
 #ifndef CTR_OCC6_MIN_TRIS
 #define CTR_OCC6_MIN_TRIS 1000  // scenes with at least this many mesh triangles use the 6-waves-per-SIMD build
 #endif
+#ifndef CTR_FIRST_ORDER_MIN_TILES
+#define CTR_FIRST_ORDER_MIN_TILES 8192  // smaller launches start in image order: one round of waves, no tail to shape
+#endif
 #ifndef CTR_ORDER_PERIOD
 #define CTR_ORDER_PERIOD 8  // launches between rebuilds of the tile order
 #endif
@@ -283,7 +286,18 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
   //  of a mesh / sphere, computed and sorted by a pre-pass — was built and measured in round 2: the expensive
   //  tiles of these scenes are speckle along shadow edges and reflections, not the tiles that look at an
   //  object, and the pre-pass cost more than it won; DESIGN.md "First launch")
-  if (same) L.order = s->d_order; else s->order_age = 0;
+  if (same) L.order = s->d_order;
+  else {
+    s->order_age = 0;
+    // a shape nothing is known about: centre-out instead of image order (render_kernel.hip first_order) — for
+    // launches large enough to have a tail and scenes heavy enough (the triangle count that also picks the 6-wave
+    // build) for the ~8 us of the order kernel to pay: bunny -5.5 %, 64k bunny -2 %, C4 -2 %, but mirror.json (924
+    // triangles, 0.2 ms) +4 % (profiles/r02/first_launch_centre_out.txt)
+    if (n >= CTR_FIRST_ORDER_MIN_TILES && s->mesh_tris >= ctr_scene::occ6_min_tris() && !(s->user_variant & CTR_VAR_IMAGE_ORDER_FIRST)) {
+      L.order = s->d_order;
+      L.order_init = 1;
+    }
+  }
   memcpy(s->order_key, key, sizeof(key));
   s->order_valid = true;  // after this launch d_order holds an order measured on this shape
   L.cost = s->d_cost;

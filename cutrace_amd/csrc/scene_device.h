@@ -152,6 +152,8 @@ struct RenderLaunch {
   uint32_t *cost;         // out: per-wave cost of this launch
   uint32_t *order_next;   // out (or null = keep the old order): waves sorted by descending cost
                           // (may alias `order`: written after the render)
+  uint32_t order_init;    // 1: no costs are known for this shape — fill `order` (writable then) with the centre-out
+                          // order before the render (render_kernel.hip first_order)
   // Host delivery (render_kernel.hip "Host delivery"; single frame only): when group_done is set, depth / color /
   // normal above are a TILE-MAJOR staging area of ctr_staging_pixels() pixels each (x1, x3, x3 floats), and the
   // frame is written into host_* — device-visible page-locked host memory, compact row-major as in ctr_render — by

@@ -247,12 +247,15 @@ int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
 #define CTR_VAR_EXACT_POW 32u     /* exact specular term: pow() in f64 (<=1 ulp of glibc powf), IEEE half-vector normalisation */
 #define CTR_VAR_STATS 16u         /* diagnostic build: print wave-level work counters to stderr */
 #define CTR_VAR_NO_REORDER 256u   /* always dispatch tiles in image order (see below) */
+#define CTR_VAR_IMAGE_ORDER_FIRST 2048u /* the first launch of a shape dispatches its tiles in image order instead of centre-out */
 #define CTR_VAR_NO_DIRECT 1024u   /* ctr_render / ctr_render_multi: page-locked destinations get device buffers + DMA instead of delivery by the kernels */
 #define CTR_VAR_NO_OCC6 512u      /* never pick the build compiled for 6 waves per SIMD (chosen for scenes with >= 1000 mesh triangles) */
 /* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
  * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles
  * first, which removes the tail of slow waves at the end of a frame.  Results do not depend on the
- * order.  The first launch of a shape, and every launch under CTR_VAR_NO_REORDER, uses image order.
+ * order.  The first launch of a shape has no costs to go by: image order, or — large frames of scenes with >= 1000 mesh
+ * triangles — blocks of tiles from the image centre outwards (CTR_VAR_IMAGE_ORDER_FIRST: always image order).  Every
+ * launch under CTR_VAR_NO_REORDER uses image order.
  * Consequence: launches on ONE scene handle must be ordered by the caller (one stream at a time).
  * The first launch of a shape allocates the (small) cost/order buffers with hipMalloc: make that
  * launch before capturing ctr_render_device into a HIP graph, or capture under CTR_VAR_NO_REORDER. */

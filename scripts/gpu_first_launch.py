@@ -41,6 +41,6 @@ for name, path, b in todo:
     for _ in range(4):
         ds.render(bounces=b, pinned=True)
     tot_pinned = statistics.median(ds.render(bounces=b, pinned=True)["total_ms"] for _ in range(5))
-    print(f"{name:13s} first launch (image order) {res['image']:.3f} ms, new shape on warm buffers {min(warm['image']):.3f} ms; steady {steady:.3f} ms "
+    print(f"{name:13s} first launch (no costs yet: centre-out or image order) {res['image']:.3f} ms, new shape on warm buffers {min(warm['image']):.3f} ms; steady {steady:.3f} ms "
           f"(first/steady = {res['image'] / steady:.3f}); ctr_render total_ms: pageable {tot_pageable:.2f} (fresh buffers per call {tot_fresh:.2f}), "
           f"page-locked by DMA {tot_dma:.2f}, page-locked delivered by the kernel {tot_pinned:.2f}", flush=True)

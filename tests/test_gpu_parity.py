@@ -572,3 +572,23 @@ def test_host_delivery_odd_sizes_and_separate_buffers(ca, w, h):
         assert same_bits(color.numpy().reshape(n, w, 3), ref["color"])
         assert same_bits(normal.numpy().reshape(n, w, 3), ref["normal"])
         assert int(stats.ray_count) == ref["ray_count"]
+
+
+@pytest.mark.parametrize("w,h,rows", [(1000, 700, None), (1920, 1080, (0, 1080, 8, 1, 2)), (1027, 1033, (16, 1001))])
+def test_first_launch_centre_out_order_is_a_permutation(ca, w, h, rows):
+    """The first launch of a shape dispatches its tiles centre-out (render_kernel.hip first_order; scenes with >= 1000 mesh
+    triangles, >= 8192 tiles).  A tile left out or visited twice would show as a wrong pixel: the first frame of a fresh
+    handle — ragged blocks of tiles, interleaved row parts, a row sub-range — against image order, bitwise, plus the ray
+    count; then the second frame (measured order)."""
+    s = load_scene(ca, "bunny", w, h)
+    ref = ca.DeviceScene(s)
+    ref.set_variant(ca.VAR_NO_REORDER)
+    want = ref.render(bounces=2, rows=rows)
+    ds = ca.DeviceScene(s)
+    for call in range(2):
+        got = ds.render(bounces=2, rows=rows)
+        for k in ("depth", "normal", "color"):
+            assert same_bits(got[k], want[k]), (call, k)
+        assert got["ray_count"] == want["ray_count"] and got["max_depth"] == want["max_depth"]
+    costs = ds.tile_costs()
+    assert costs.size == ((w + 7) // 8) * ((want["depth"].shape[0] + 7) // 8) and costs.min() > 0   # every tile ran
