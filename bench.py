@@ -365,7 +365,7 @@ def main():
                               f"{frames} frame(s)/step row-tiled over {world} GPU(s), "
                               + ("frame f gathered to rank f mod N" if tiler.rotate_roots else "gather to rank 0"),
                   "tile_order": "expensive tiles first, costs recorded by the previous launch of the same "
-                                "shape (first launch of a shape: image order)",
+                                "shape (first launch of a shape: blocks of tiles from the image centre outwards)",
                   "kernel_ms_image_order": kern_io,
                   "frames_per_step": frames, "rays_per_step": rays_step,
                   "frame_ms": dt_max / args.steps * 1e3 / frames,
