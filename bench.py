@@ -117,7 +117,7 @@ def extras(ca, hs, args, ds):
     w, h = hs.size
     out = {}
     # (1) what the drop-in `cutrace <scene.json>` gets (main.cu:30: one frame per process): the FIRST launch of the
-    #     shape on a fresh scene handle, in image order — the kernel alone (device buffers), and the whole host-buffer
+    #     shape on a fresh scene handle, before any costs are known — the kernel alone (device buffers), and the whole host-buffer
     #     call into page-locked memory, which the kernel delivers itself while it renders (= the reference's
     #     total_ms, kernel.hpp:88,126); then the same call in steady state, with the frame leaving by one DMA after
     #     the kernel instead (CTR_VAR_NO_DIRECT), and through pageable memory
