@@ -898,6 +898,23 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   }
   HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
+  if (direct && getenv("CUTRACE_VERIFY_DELIVERY")) {
+    // Debug aid for the kernel's own delivery (render_kernel.hip "Host delivery" relies on write-through stores and
+    // scoped loads instead of fences): the tile-major staging copy of the frame is still on the device — fetch it
+    // and compare every pixel with what arrived in the caller's buffers.
+    std::vector<float> stg(7 * spx);
+    HIP_TRY(hipMemcpy(stg.data(), s->d_out, sizeof(float) * 7 * spx, hipMemcpyDeviceToHost));
+    const uint32_t w = s->cam.w, tiles_x = (w + 7) / 8;
+    uint64_t bad = 0;
+    for (uint32_t y = 0; y < L.rows.n_rows; y++)
+      for (uint32_t x = 0; x < w; x++) {
+        const size_t at = (size_t)y * w + x, sp = ((size_t)(y / 8) * tiles_x + x / 8) * 64 + (y % 8) * 8 + x % 8;
+        bool ok = memcmp(&depth[at], &stg[sp], 4) == 0;
+        ok = ok && memcmp(&color3[3 * at], &stg[spx + 3 * sp], 12) == 0 && memcmp(&normal3[3 * at], &stg[4 * spx + 3 * sp], 12) == 0;
+        bad += ok ? 0 : 1;
+      }
+    if (bad) return fail(CTR_E_INVALID, "CUTRACE_VERIFY_DELIVERY: " + std::to_string(bad) + " delivered pixels differ from the staged frame");
+  }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
   unsigned long long cnt[16];

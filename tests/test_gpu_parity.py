@@ -592,3 +592,15 @@ def test_first_launch_centre_out_order_is_a_permutation(ca, w, h, rows):
         assert got["ray_count"] == want["ray_count"] and got["max_depth"] == want["max_depth"]
     costs = ds.tile_costs()
     assert costs.size == ((w + 7) // 8) * ((want["depth"].shape[0] + 7) // 8) and costs.min() > 0   # every tile ran
+
+
+def test_delivery_self_check(ca, monkeypatch):
+    """CUTRACE_VERIFY_DELIVERY=1 makes ctr_render compare what the kernel delivered into page-locked memory with the staged
+    frame it still holds on the device, pixel by pixel (a debug aid): it must pass, at full size and at a ragged one."""
+    monkeypatch.setenv("CUTRACE_VERIFY_DELIVERY", "1")
+    for (w, h) in ((1920, 1080), (333, 131)):
+        s = load_scene(ca, "bunny", w, h)
+        ds = ca.DeviceScene(s)
+        for _ in range(2):
+            r = ds.render(bounces=3, pinned=True)     # raises if the self-check fails
+        assert r["ray_count"] > 0
