@@ -127,6 +127,20 @@ def test_nccl_backend_world_one(ca):
         t = torch.ones(1, device=dev)
         dist.all_reduce(t)     # one real RCCL collective on this box
         dist.barrier()
+        # the primitive the tiler's exchange is made of (grouped ncclSend / ncclRecv through batch_isend_irecv), on the
+        # real backend: three pieces sent to and received from the only rank there is, on a side stream like the tiler's
+        src = [torch.arange(1000 * (k + 1), dtype=torch.float32, device=dev) + k for k in range(3)]
+        dst = [torch.zeros_like(x) for x in src]
+        ops = [dist.P2POp(dist.isend, x, 0) for x in src] + [dist.P2POp(dist.irecv, y, 0) for y in dst]
+        works = dist.batch_isend_irecv(ops)
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            for wk in works:
+                wk.wait()
+            got = [y.clone() for y in dst]
+        side.synchronize()
+        for x, y in zip(src, got):
+            assert torch.equal(x, y)
         want = ds.render(bounces=5)
         assert same_bits(tiler.final["depth"][0].cpu().numpy(), want["depth"])
         assert same_bits(tiler.final["color"][0].cpu().numpy(), want["color"])
