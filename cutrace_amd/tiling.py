@@ -65,6 +65,8 @@ class FrameTiler:
         self.gathered = None
         self.final = None
         self.pending = [None] * self.slots      # outstanding exchange per slot (list of works)
+        self._ops = [None] * self.slots         # the exchange's send / receive descriptors per slot
+        self._parts = {}                        # (slot, my frame) -> pointer table of the re-interleave launch
         self.side = None                         # side stream for the re-interleave
         self.assembled = [None] * self.slots     # event: slot's frames are in `final`
         self.is_cuda = self.device.type == "cuda"
@@ -143,19 +145,7 @@ class FrameTiler:
             self.final["color"] = buf[c0:n0].view(F, h, w, 3)
             self.final["normal"] = buf[n0:e].view(F, h, w, 3)
             return
-        P = self.P
-        ops = []
-        # every rank walks the frames in the same order, so the sends and receives of any pair of ranks match up
-        for f in range(self.frames):
-            root = self.root_of(f)
-            if root == self.rank:
-                g = self.gathered[slot][self.final_frames.index(f)]
-                for q in range(self.world):
-                    if q != self.rank:
-                        ops += [dist.P2POp(dist.irecv, g[q][0:P], q), dist.P2POp(dist.irecv, g[q][P:4 * P], q),
-                                dist.P2POp(dist.irecv, g[q][4 * P:7 * P], q)]
-            else:
-                ops += [dist.P2POp(dist.isend, t, root) for t in self.pieces(slot, f)]
+        ops = self._exchange_ops(slot)
         works = dist.batch_isend_irecv(ops) if ops else []
         if not self.final_frames:
             self.pending[slot] = works
@@ -174,6 +164,25 @@ class FrameTiler:
             for wk in works:
                 wk.wait()
             self.assemble(slot)
+
+    def _exchange_ops(self, slot):
+        """The sends and receives of one step for `slot` (its buffers never move: built once, reused every step).
+        Every rank walks the frames in the same order, so the sends and receives of any pair of ranks match up."""
+        if self._ops[slot] is None:
+            P = self.P
+            ops = []
+            for f in range(self.frames):
+                root = self.root_of(f)
+                if root == self.rank:
+                    g = self.gathered[slot][self.final_frames.index(f)]
+                    for q in range(self.world):
+                        if q != self.rank:
+                            ops += [dist.P2POp(dist.irecv, g[q][0:P], q), dist.P2POp(dist.irecv, g[q][P:4 * P], q),
+                                    dist.P2POp(dist.irecv, g[q][4 * P:7 * P], q)]
+                else:
+                    ops += [dist.P2POp(dist.isend, t, root) for t in self.pieces(slot, f)]
+            self._ops[slot] = ops
+        return self._ops[slot]
 
     def finish(self):
         """Drain every outstanding exchange / re-interleave."""
@@ -216,11 +225,14 @@ class FrameTiler:
         W = self.world
         stream = torch.cuda.current_stream(self.device).cuda_stream
         for i, f in enumerate(self.final_frames):
-            src = self._sources(slot, i, f)
-            parts = (_lib.ReintPart * W)()
-            for p in range(W):
-                r = (p - f * self.part_stride) % W  # the rank that rendered part p of frame f
-                parts[p].d_depth, parts[p].d_color3, parts[p].d_normal3 = (t.data_ptr() for t in src[r])
+            parts = self._parts.get((slot, i))
+            if parts is None:  # (the buffers never move: the pointer table is built once)
+                src = self._sources(slot, i, f)
+                parts = (_lib.ReintPart * W)()
+                for p in range(W):
+                    r = (p - f * self.part_stride) % W  # the rank that rendered part p of frame f
+                    parts[p].d_depth, parts[p].d_color3, parts[p].d_normal3 = (t.data_ptr() for t in src[r])
+                self._parts[(slot, i)] = parts
             st = L.ctr_reinterleave_device(parts, W, self.block_rows, self.w, self.h, self.final["depth"][i].data_ptr(),
                                            self.final["color"][i].data_ptr(), self.final["normal"][i].data_ptr(), stream)
             if st:
