@@ -99,6 +99,7 @@ constexpr int WG_THREADS = 64 * WAVES_PER_WG;
 
 struct V3 { float x, y, z; };
 typedef float float2_ __attribute__((ext_vector_type(2)));
+typedef float float4_ __attribute__((ext_vector_type(4)));
 // d = s * v.{lo|hi} - k.{lo|hi} for both halves of the SGPR pair s: v_pk_fma_f32 with op_sel choosing
 // which half of the VGPR pairs v and k is broadcast (vsel/ksel: 0 = low, 1 = high), k negated
 // d = s * v.{lo|hi} (both halves of the SGPR pair s times ONE broadcast half of the VGPR pair v)
@@ -145,6 +146,20 @@ __device__ __forceinline__ float slab_hi4(float ax, float bx, float ay, float by
   asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(ax), "v"(bx));
   asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(ay), "v"(by));
   asm("v_max_f32 %0, %1, %2" : "=v"(z) : "v"(az), "v"(bz));
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(mx));
+  return r;
+}
+// entry / exit distance of a box whose near and far plane per axis are already known (octant path: the wave's rays
+// share their direction signs): max(near distances, mn) / min(far distances, mx); a NaN operand drops out as above
+__device__ __forceinline__ float oct_lo4(float x, float y, float z, float mn) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(mn));
+  return r;
+}
+__device__ __forceinline__ float oct_hi4(float x, float y, float z, float mx) {
+  float r;
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(mx));
   return r;
@@ -248,6 +263,7 @@ struct KArgs {
   uint32_t frames;    // LDS stack frames per lane: the recursion depth that can be reached (bounces, or 1 when no
                       // material reflects or transmits: ray_color then never recurses)
   const CADDR uint32_t *order;  // dispatch slot -> wave (tile) index, or null = identity
+  uint32_t n_slots;             // dispatch slots of this launch: the number of waves, or more when the order pads (XCD bands)
   uint32_t *cost;               // per wave (tile): shader-clock ticks it took, or null
   // "Host delivery" (below): null group_done = the outputs are written in place
   float *host_depth, *host_color, *host_normal;
@@ -289,7 +305,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast,
   // and how many of the 64 lanes had a use for the wave-level work: [6] lanes whose ray meets one of the
   // visited node's child boxes, [7] lanes inside the leaf's box at a prefilter, [8] lanes in an exact test
-  unsigned long long st[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // and what a walk by every lane for itself would take, in steps of the whole wave: per mesh entry the LARGEST number of
+  // [9] node visits and [10] triangle tests any one lane has a use for, [11] octant-path mesh entries
+  unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef CTR_TIMING
   // diagnostic build only: shader-clock stamps per wave -> shards[4..13] = {cast setup, planes, object
   // loop, top-level walk + mesh AABB, mesh entry setup, BVH walk without leaves, leaves, radiance
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   const uint32_t tiles_x = (w + TW - 1) / TW;
   const uint32_t tiles_y = (A.rows.n_rows + TH - 1) / TH;
   const uint32_t tiles_frame = tiles_x * tiles_y;
-  if (slot >= tiles_frame * A.n_frames) return;  // whole wave exits together
+  if (slot >= A.n_slots) return;  // whole wave exits together
   // Dispatch order.  Waves differ 10x in cost and the hardware hands them out in blockIdx order, so
   // with tiles in image order the last quarter of a frame is a tail of a few slow waves on an
   // otherwise empty GPU.  Every launch records what each tile cost; the next launch of the same
@@ -726,6 +744,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           const uint32_t beg = O.tri_begin, cnt = O.tri_count;
           if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
           if (STATS) st[4]++;
+          uint32_t pl_nodes = 0, pl_tris = 0;  // STATS: this lane's own share of the mesh entry's node visits / triangle tests
           // ---- mesh::intersect, default_schema.hpp:125-144: smallest valid t, FIRST triangle in
           //      file order on ties (strict < over file order)  ==  lexicographic min of (t, orig) ----
           float mt = INFINITY;
@@ -742,7 +761,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
           auto tri_test = [&](const auto &T, uint32_t tri_index, mask_t lanes_m) {
             mask_t c_m = lanes_m;
-            if (STATS) { st[2]++; st[7] += __builtin_popcountll(lanes_m); }
+            if (STATS) { st[2]++; st[7] += __builtin_popcountll(lanes_m); pl_tris += INVB(lanes_m) ? 1u : 0u; }
             // d = p2 - start (default_schema.hpp:58): x and y in one packed subtraction (same IEEE result)
             const float2_ dxy = ldpair2(&T.px) - ro_xy;
             const float dx = dxy.x, dy = dxy.y, dz = T.pz - ro.z;
@@ -788,7 +807,38 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                 const float third = absa - (sA1 + sA2);
                 asm("v_min3_f32 %0, %1, %2, %3" : "=v"(slack) : "v"(sA1), "v"(sA2), "v"(third));
               }
-              const mask_t rej = FCMP(slack, -E, FC_OLT);
+              mask_t rej = FCMP(slack, -E, FC_OLT);
+#ifdef CTR_EXP_PF2
+              {  // diagnostic: the first prefilter stage a second time (ray direction made opaque: no merging)
+                float rx = rd.x, ry = rd.y, rz = rd.z;
+                PIN3(rx, ry, rz);
+                const float alpha2 = __builtin_fmaf(rx, T.nx, __builtin_fmaf(ry, T.ny, rz * T.nz));
+                float2_ q2_xy, q2_z;
+                q2_xy.x = __builtin_fmaf(dy, rz, -(dz * ry));
+                q2_xy.y = __builtin_fmaf(dz, rx, -(dx * rz));
+                q2_z.x = __builtin_fmaf(dx, ry, -(dy * rx));
+                q2_z.y = 0.0f;
+                float2_ m2;
+                PKMULB(m2, ldpair(T.ab[0]), q2_xy, 0);
+                PKFMAB(m2, ldpair(T.ab[1]), q2_xy, 1, m2);
+                PKFMAB(m2, ldpair(T.ab[2]), q2_z, 0, m2);
+                const uint32_t sgn2 = __float_as_uint(alpha2) & 0x80000000u;
+                float2_ s2;
+                s2.x = __uint_as_float(sgn2 | 0x3f800000u);
+                s2.y = 0.0f;
+                float2_ sm2;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(sm2) : "v"(m2), "v"(s2));
+                const float absa2 = fabsf(alpha2);
+                float dmax2 = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+                asm volatile("" : "+v"(dmax2));
+                const uint32_t e_a2 = __float_as_uint(dmax2 * T.ke), e_b2 = __float_as_uint(T.ke2);
+                const float E2 = __uint_as_float(e_a2 > e_b2 ? e_a2 : e_b2) * cmax;
+                float slack2;
+                const float third2 = absa2 - (sm2.y + sm2.x);
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(slack2) : "v"(sm2.y), "v"(sm2.x), "v"(third2));
+                rej &= FCMP(slack2, -E2, FC_OLT);
+              }
+#endif
               flat_m = FCMP(absa, E, FC_OLE);  // alpha within rounding of 0: always a candidate
               c_m = lanes_m & (~rej | flat_m);
               if (c_m == 0ull) return;
@@ -922,25 +972,115 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             const uint32_t neg_bits = lead_shadow ^ (nb_x | (nb_y << 1) | (nb_z << 2));
             // the nine per-ray constants of the box test, two to a register pair; PKFMA picks the half it
             // needs with op_sel, so packing costs no extra registers
-            const float2_ c_rxy = {ria.x, ria.y}, c_rzk = {ria.z, ka.x}, c_kyz = {ka.y, ka.z};
-            const float2_ c_bxy = {kb.x, kb.y}, c_bz = {kb.z, 0.0f};
+            // Octant path.  A slab's entry distance is min(t1, t2) and its exit max(t1, t2) only because a lane does not
+            // know its ray's direction sign at compile time; which of the two it is, is the sign of the reciprocal.  When
+            // every lane that needs the mesh has the SAME signs (coherent rays: nearly always) the choice is wave-uniform:
+            // the node's near and far planes are picked by the OFFSET they are loaded from (lo or hi, per axis), the
+            // per-ray constants are swapped to match once per mesh entry, and a box costs max3 + max, min3 + min and one
+            // compare instead of three min, three max on top of them (24 of a node visit's ~70 vector instructions).
+            // t1 <= t2 holds exactly (monotonic rounding of the FMAs; lo <= hi, ka >= kb for a positive reciprocal), so
+            // both forms give the same lane masks.  A wave with mixed signs takes the min/max form below.
+#ifndef CTR_NO_OCT
+            const mask_t ng_x = FCMP(ria.x, 0.0f, FC_OLT) & bb_m, ng_y = FCMP(ria.y, 0.0f, FC_OLT) & bb_m,
+                         ng_z = FCMP(ria.z, 0.0f, FC_OLT) & bb_m;
+            const bool oct_ok = (ng_x == 0ull || ng_x == bb_m) && (ng_y == 0ull || ng_y == bb_m) && (ng_z == 0ull || ng_z == bb_m);
+            const bool sw_x = oct_ok && ng_x != 0ull, sw_y = oct_ok && ng_y != 0ull, sw_z = oct_ok && ng_z != 0ull;
+            if (STATS && oct_ok) st[11]++;
+#else
+            const bool oct_ok = false, sw_x = false, sw_y = false, sw_z = false;
+#endif
+            // byte offsets inside a DNode4 of the planes multiplied first (k1) and second (k2) on each axis: (lo, hi), or
+            // (hi, lo) on an axis the whole wave looks down
+            const uint32_t o1x = sw_x ? 48u : 0u, o1y = sw_y ? 64u : 16u, o1z = sw_z ? 80u : 32u;
+            const uint32_t o2x = sw_x ? 0u : 48u, o2y = sw_y ? 16u : 64u, o2z = sw_z ? 32u : 80u;
+            const V3 k1 = mk(sw_x ? kb.x : ka.x, sw_y ? kb.y : ka.y, sw_z ? kb.z : ka.z);
+            const V3 k2 = mk(sw_x ? ka.x : kb.x, sw_y ? ka.y : kb.y, sw_z ? ka.z : kb.z);
+            const float2_ c_rxy = {ria.x, ria.y}, c_rzk = {ria.z, k1.x}, c_kyz = {k1.y, k1.z};
+            const float2_ c_bxy = {k2.x, k2.y}, c_bz = {k2.z, 0.0f};
             // children (c, c+1) of one node: six v_pk_fma_f32 give the six slab distances of both boxes;
             // a lane takes a child unless it misses for certain: max(entry, min_t) > min(exit, lim)
             // (v_min/v_max drop a NaN operand, a NaN that survives compares false -> entered)
-            auto box_hits2 = [&](const CADDR DNode4 &N, int c, mask_t &ha, mask_t &hb) {
-              float2_ t1x, t1y, t1z, t2x, t2y, t2z;
-              PKFMA(t1x, ldpair2(&N.lo[0][c]), c_rxy, 0, c_rzk, 1);
-              PKFMA(t1y, ldpair2(&N.lo[1][c]), c_rxy, 1, c_kyz, 0);
-              PKFMA(t1z, ldpair2(&N.lo[2][c]), c_rzk, 0, c_kyz, 1);
-              PKFMA(t2x, ldpair2(&N.hi[0][c]), c_rxy, 0, c_bxy, 0);
-              PKFMA(t2y, ldpair2(&N.hi[1][c]), c_rxy, 1, c_bxy, 1);
-              PKFMA(t2z, ldpair2(&N.hi[2][c]), c_rzk, 0, c_bz, 0);
-              const float lo_a = slab_lo4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, min_t);
-              const float hi_a = slab_hi4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, lim);
-              const float lo_b = slab_lo4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, min_t);
-              const float hi_b = slab_hi4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, lim);
-              ha = bb_m & ~FCMP(lo_a, hi_a, FC_OGT);
-              hb = bb_m & ~FCMP(lo_b, hi_b, FC_OGT);
+            // the planes of the four children, one SGPR quad per axis and side, loaded from the offsets chosen above
+            // (s_load_dwordx4 with an SGPR offset: written out, because the compiler turns a variable offset into an
+            // address computation and a wait per pair)
+            // (the child descriptors and the order axis travel in the same batch of loads, one wait for all)
+            typedef uint32_t uint4_ __attribute__((ext_vector_type(4)));
+            auto box_hits4 = [&](const CADDR DNode4 *np, mask_t &h0, mask_t &h1, mask_t &h2, mask_t &h3, uint4_ &kids, uint32_t &axis) {
+              float4_ P1x, P1y, P1z, P2x, P2y, P2z;
+              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1x) : "s"(np), "s"(o1x));
+              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1y) : "s"(np), "s"(o1y));
+              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1z) : "s"(np), "s"(o1z));
+              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2x) : "s"(np), "s"(o2x));
+              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2y) : "s"(np), "s"(o2y));
+              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2z) : "s"(np), "s"(o2z));
+              asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=&s"(kids) : "s"(np));
+              asm volatile("s_load_dword %0, %1, 0x70" : "=&s"(axis) : "s"(np));
+              asm volatile("s_waitcnt lgkmcnt(0)"
+                           : "+s"(P1x), "+s"(P1y), "+s"(P1z), "+s"(P2x), "+s"(P2y), "+s"(P2z), "+s"(kids), "+s"(axis));
+#ifdef CTR_EXP_NLOAD2
+              // diagnostic: the node's load round trip a second time (dependent on the first through the order axis)
+              {
+                const CADDR DNode4 *np2 = np + (axis >> 8);  // axis < 3: the same node
+                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1x) : "s"(np2), "s"(o1x));
+                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1y) : "s"(np2), "s"(o1y));
+                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1z) : "s"(np2), "s"(o1z));
+                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2x) : "s"(np2), "s"(o2x));
+                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2y) : "s"(np2), "s"(o2y));
+                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2z) : "s"(np2), "s"(o2z));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(P1x), "+s"(P1y), "+s"(P1z), "+s"(P2x), "+s"(P2y), "+s"(P2z));
+              }
+#endif
+#define CTR_PAIR_T(SEL0, SEL1)                                                       \
+  float2_ t1x, t1y, t1z, t2x, t2y, t2z;                                              \
+  PKFMA(t1x, __builtin_shufflevector(P1x, P1x, SEL0, SEL1), c_rxy, 0, c_rzk, 1);     \
+  PKFMA(t1y, __builtin_shufflevector(P1y, P1y, SEL0, SEL1), c_rxy, 1, c_kyz, 0);     \
+  PKFMA(t1z, __builtin_shufflevector(P1z, P1z, SEL0, SEL1), c_rzk, 0, c_kyz, 1);     \
+  PKFMA(t2x, __builtin_shufflevector(P2x, P2x, SEL0, SEL1), c_rxy, 0, c_bxy, 0);     \
+  PKFMA(t2y, __builtin_shufflevector(P2y, P2y, SEL0, SEL1), c_rxy, 1, c_bxy, 1);     \
+  PKFMA(t2z, __builtin_shufflevector(P2z, P2z, SEL0, SEL1), c_rzk, 0, c_bz, 0);
+#define CTR_PAIR_OCT(SEL0, SEL1, ha, hb)                                             \
+  {                                                                                  \
+    CTR_PAIR_T(SEL0, SEL1)                                                           \
+    const float lo_a = oct_lo4(t1x.x, t1y.x, t1z.x, min_t), hi_a = oct_hi4(t2x.x, t2y.x, t2z.x, lim); \
+    const float lo_b = oct_lo4(t1x.y, t1y.y, t1z.y, min_t), hi_b = oct_hi4(t2x.y, t2y.y, t2z.y, lim); \
+    ha = bb_m & ~FCMP(lo_a, hi_a, FC_OGT);                                           \
+    hb = bb_m & ~FCMP(lo_b, hi_b, FC_OGT);                                           \
+  }
+#define CTR_PAIR_MM(SEL0, SEL1, ha, hb)                                              \
+  {                                                                                  \
+    CTR_PAIR_T(SEL0, SEL1)                                                           \
+    const float lo_a = slab_lo4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, min_t);    \
+    const float hi_a = slab_hi4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, lim);      \
+    const float lo_b = slab_lo4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, min_t);    \
+    const float hi_b = slab_hi4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, lim);      \
+    ha = bb_m & ~FCMP(lo_a, hi_a, FC_OGT);                                           \
+    hb = bb_m & ~FCMP(lo_b, hi_b, FC_OGT);                                           \
+  }
+              if (oct_ok) {
+                CTR_PAIR_OCT(0, 1, h0, h1)
+                CTR_PAIR_OCT(2, 3, h2, h3)
+              } else {
+                CTR_PAIR_MM(0, 1, h0, h1)
+                CTR_PAIR_MM(2, 3, h2, h3)
+              }
+#ifdef CTR_EXP_BOX2
+              // diagnostic: the box arithmetic a second time (operands made opaque so that it is not merged with the first)
+              {
+                mask_t x0, x1, x2, x3;
+                asm volatile("" : "+s"(P1x), "+s"(P1y), "+s"(P1z), "+s"(P2x), "+s"(P2y), "+s"(P2z));
+                if (oct_ok) {
+                  CTR_PAIR_OCT(0, 1, x0, x1)
+                  CTR_PAIR_OCT(2, 3, x2, x3)
+                } else {
+                  CTR_PAIR_MM(0, 1, x0, x1)
+                  CTR_PAIR_MM(2, 3, x2, x3)
+                }
+                h0 &= x0; h1 &= x1; h2 &= x2; h3 &= x3;
+              }
+#endif
+#undef CTR_PAIR_T
+#undef CTR_PAIR_OCT
+#undef CTR_PAIR_MM
             };
             auto leaf = [&](uint32_t desc, mask_t lanes) {
               TSTAMP(t_leaf0);
@@ -972,15 +1112,15 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 #endif
             for (;;) {
               if (STATS) st[1]++;
-              const CADDR DNode4 &N = nodes4[cur];
               mask_t h0, h1, h2, h3;
-              box_hits2(N, 0, h0, h1);
-              box_hits2(N, 2, h2, h3);
-              if (STATS) st[6] += __builtin_popcountll(h0 | h1 | h2 | h3);
-              const uint32_t d0 = N.child[0], d1 = N.child[1], d2 = N.child[2], d3 = N.child[3];
+              uint4_ kids;
+              uint32_t n_axis;
+              box_hits4(&nodes4[cur], h0, h1, h2, h3, kids, n_axis);
+              if (STATS) { st[6] += __builtin_popcountll(h0 | h1 | h2 | h3); pl_nodes += INVB(h0 | h1 | h2 | h3) ? 1u : 0u; }
+              const uint32_t d0 = kids.x, d1 = kids.y, d2 = kids.z, d3 = kids.w;
               // children are stored sorted along the node's order axis; a wave whose lead ray points the other
               // way takes them in reverse (wave-uniform selects): e0/g0 = nearest ... e3/g3 = farthest
-              const bool rev = ((neg_bits >> N.axis) & 1u) != 0u;
+              const bool rev = ((neg_bits >> n_axis) & 1u) != 0u;
               const uint32_t e0 = rev ? d3 : d0, e1 = rev ? d2 : d1, e2 = rev ? d1 : d2, e3 = rev ? d0 : d3;
               const mask_t g0 = rev ? h3 : h0, g1 = rev ? h2 : h1, g2 = rev ? h1 : h2, g3 = rev ? h0 : h3;
               // ONE pass, farthest child first: a hit leaf is tested at once; a hit inner child becomes the node to
@@ -1020,6 +1160,15 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                 if (bb_m == 0ull) break;
               }
             }
+          }
+          if (STATS) {
+            for (int off = 32; off > 0; off >>= 1) {
+              const uint32_t on = (uint32_t)__shfl_xor((int)pl_nodes, off), ot = (uint32_t)__shfl_xor((int)pl_tris, off);
+              pl_nodes = on > pl_nodes ? on : pl_nodes;
+              pl_tris = ot > pl_tris ? ot : pl_tris;
+            }
+            st[9] += (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_nodes);
+            st[10] += (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_tris);
           }
           if (ANYHIT) live = live && !INVB(bb0_m & ~bb_m);  // lanes retired inside the mesh
           ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
@@ -1347,7 +1496,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     }
     unsigned long long *sh = counters + (size_t)(wave % CTR_SHARDS) * CTR_SHARD_WORDS;
     if (STATS && lane == 0) {
-      for (int q = 0; q < 9; q++) atomicAdd(&sh[4 + q], st[q]);
+      for (int q = 0; q < 12; q++) atomicAdd(&sh[4 + q], st[q]);
     }
 #ifdef CTR_TIMING
     if (lane == 0) {
@@ -1367,7 +1516,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 // block of CTR_SHARDS threads: thread t owns shard t; wave-level reduction, then one LDS atomic per
 // wave and word; adds into out[0..13] (max for word 1) and zeroes the shards for the next launch
 __device__ void fold_block(unsigned long long *__restrict__ shards, unsigned long long *__restrict__ out) {
-  constexpr int NW = 14;
+  constexpr int NW = 16;
   __shared__ unsigned long long acc[NW];
   if (threadIdx.x < NW) acc[threadIdx.x] = 0ull;
   __syncthreads();
@@ -1637,6 +1786,7 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.nf = L.need_cold_frames ? 10u : 4u;
   A.frames = (uint32_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1);
   A.order = (const CADDR uint32_t *)L.order;
+  A.n_slots = (L.order && L.order_slots) ? L.order_slots : (uint32_t)launch_waves(L);
   A.cost = L.cost;
   const bool host_delivery = (KV & KV_HOSTOUT) != 0;
   if (host_delivery != (L.group_done != nullptr)) return (int)hipErrorInvalidValue;
@@ -1651,7 +1801,7 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   const uint64_t waves = launch_waves(L);
   if (waves > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
   if (waves == 0) return 0;
-  const uint32_t grid = (uint32_t)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
+  const uint32_t grid = (uint32_t)(((uint64_t)A.n_slots + WAVES_PER_WG - 1) / WAVES_PER_WG);
   // counters go through the scene's shard buffer and are folded into the caller's words afterwards
   unsigned long long *shards = L.counters ? L.shards : nullptr;
   if (L.order_init && L.order) {
