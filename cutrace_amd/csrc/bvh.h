@@ -15,7 +15,6 @@
 #ifndef CUTRACE_AMD_BVH_H
 #define CUTRACE_AMD_BVH_H
 
-#include <stddef.h>
 #include <stdint.h>
 #include <vector>
 
@@ -52,8 +51,6 @@ struct DNode4 {
   uint32_t pad[3];
 };
 static_assert(sizeof(DNode4) == 128, "DNode4 must be two 64-byte lines");
-static_assert(offsetof(DNode4, lo) == 0 && offsetof(DNode4, hi) == 48 && offsetof(DNode4, child) == 96,
-              "render_kernel.hip (octant path) loads a node's planes by byte offset");
 #define BVH4_MAX_DEPTH 20  // the walk pushes at most 3 entries per level onto a 64-entry stack
 
 struct BvhInput {

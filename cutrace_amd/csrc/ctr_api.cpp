@@ -168,11 +168,6 @@ struct ctr_scene {
   uint64_t order_cap = 0;
   uint64_t order_key[6] = {0, 0, 0, 0, 0, 0};
   bool order_valid = false;
-  // XCD bands (experiment, CUTRACE_XCD_BANDS): a padded order that keeps each XCD's tiles in one band of the image
-  uint32_t *d_order_x = nullptr;
-  uint64_t order_x_cap = 0, order_x_key[6] = {0, 0, 0, 0, 0, 0};
-  uint32_t order_x_slots = 0;
-  bool order_x_valid = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mtx;
 
@@ -316,72 +311,6 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
   s->order_view = view;
   if (s->order_age < 2 || !same_view || s->order_age % CTR_ORDER_PERIOD == 0) L.order_next = s->d_order;
   s->order_age++;
-  if (s->order_x_valid && memcmp(key, s->order_x_key, sizeof(key)) == 0) {
-    L.order = s->d_order_x;
-    L.order_slots = s->order_x_slots;
-    L.order_init = 0;
-  }
-  return CTR_OK;
-}
-
-// XCD bands.  Workgroups are dealt round-robin over the 8 XCDs (slot s runs on XCD s % 8), each with its own 4 MB
-// L2.  An order sorted by cost alone gives every XCD tiles from all over the image, so every L2 sees the whole scene;
-// when a mesh is larger than one L2 (64 000 triangles: 8 MB) the records are then re-fetched from memory all frame
-// long.  Here the tiles are cut into `nb` bands of equal measured cost along the image, band k's tiles sorted by cost
-// go to the slots of XCD k, and shorter bands are padded with entries that start an empty wave.
-int build_xcd_order(ctr_scene *s, const RenderLaunch &L, int nb, int mode) {
-  const uint64_t n = ctr_launch_waves(L);
-  if (n == 0 || n > 0x0FFFFFFFull || !s->d_cost) return CTR_OK;
-  std::vector<uint32_t> cost(n);
-  HIP_TRY(hipMemcpy(cost.data(), s->d_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  const uint32_t tiles_x = (L.w + 7) / 8, tiles_y = (uint32_t)(n / tiles_x);
-  std::vector<uint32_t> seq(n);
-  if (mode == 1) {  // column-major: vertical strips
-    size_t q = 0;
-    for (uint32_t x = 0; x < tiles_x; x++)
-      for (uint32_t y = 0; y < tiles_y; y++) seq[q++] = y * tiles_x + x;
-  } else if (mode == 2) {  // blocks of 16 x 16 tiles, boustrophedon
-    size_t q = 0;
-    const uint32_t B = 16, nbx = (tiles_x + B - 1) / B, nby = (tiles_y + B - 1) / B;
-    for (uint32_t by = 0; by < nby; by++)
-      for (uint32_t bxi = 0; bxi < nbx; bxi++) {
-        const uint32_t bx = (by & 1) ? nbx - 1 - bxi : bxi;
-        for (uint32_t y = by * B; y < tiles_y && y < (by + 1) * B; y++)
-          for (uint32_t x = bx * B; x < tiles_x && x < (bx + 1) * B; x++) seq[q++] = y * tiles_x + x;
-      }
-  } else {
-    for (uint64_t i = 0; i < n; i++) seq[i] = (uint32_t)i;
-  }
-  double total = 0;
-  for (uint64_t i = 0; i < n; i++) total += cost[i];
-  std::vector<std::vector<uint32_t>> band(nb);
-  double acc = 0;
-  for (uint64_t i = 0; i < n; i++) {
-    int k = (int)(acc * nb / (total > 0 ? total : 1.0));
-    if (k >= nb) k = nb - 1;
-    band[k].push_back(seq[i]);
-    acc += cost[seq[i]];
-  }
-  size_t max_len = 0;
-  for (auto &b : band) {
-    std::stable_sort(b.begin(), b.end(), [&](uint32_t a, uint32_t c) { return cost[a] > cost[c]; });
-    max_len = b.size() > max_len ? b.size() : max_len;
-  }
-  const uint64_t slots = (uint64_t)max_len * nb;
-  std::vector<uint32_t> order(slots, 0xFFFFFFFFu);
-  for (int k = 0; k < nb; k++)
-    for (size_t i = 0; i < band[k].size(); i++) order[i * nb + k] = band[k][i];
-  if (slots > s->order_x_cap) {
-    if (s->d_order_x) (void)hipFree(s->d_order_x);
-    s->d_order_x = nullptr;
-    s->order_x_cap = 0;
-    HIP_TRY(hipMalloc((void **)&s->d_order_x, slots * sizeof(uint32_t)));
-    s->order_x_cap = slots;
-  }
-  HIP_TRY(hipMemcpy(s->d_order_x, order.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice));
-  s->order_x_slots = (uint32_t)slots;
-  memcpy(s->order_x_key, s->order_key, sizeof(s->order_x_key));
-  s->order_x_valid = true;
   return CTR_OK;
 }
 
@@ -810,7 +739,7 @@ void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_nodes4, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
-                  (void *)s->d_out, (void *)s->d_groups, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order, (void *)s->d_order_x})
+                  (void *)s->d_out, (void *)s->d_groups, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
     if (p) (void)hipFree(p);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -987,13 +916,6 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
       }
     if (bad) return fail(CTR_E_INVALID, "CUTRACE_VERIFY_DELIVERY: " + std::to_string(bad) + " delivered pixels differ from the staged frame");
   }
-  {
-    static const int xb = [] { const char *e = getenv("CUTRACE_XCD_BANDS"); return e ? atoi(e) : 0; }();
-    static const int xmode = [] { const char *e = getenv("CUTRACE_XCD_MODE"); return e ? atoi(e) : 0; }();
-    if (xb > 0 && L.cost && !count) {
-      if ((st = build_xcd_order(s, L, xb, xmode))) return st;
-    }
-  }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
   unsigned long long cnt[16];
@@ -1002,8 +924,8 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   if (s->user_variant & CTR_VAR_STATS)
     fprintf(stderr, "cutrace_amd stats: wave_casts=%llu nodes=%llu tri_prefilter=%llu tri_exact=%llu mesh_entries=%llu "
                     "active_lanes=%llu node_lanes=%llu prefilter_lanes=%llu exact_lanes=%llu lane_max_nodes=%llu "
-                    "lane_max_tris=%llu octant_entries=%llu kernel_ms=%.3f\n", cnt[4], cnt[5],
-            cnt[6], cnt[7], cnt[8], cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14], cnt[15], ms);
+                    "lane_max_tris=%llu kernel_ms=%.3f\n", cnt[4], cnt[5],
+            cnt[6], cnt[7], cnt[8], cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14], ms);
   if (aabb_tris) *aabb_tris = cnt[2];
   if (cnt[13] && !(s->user_variant & CTR_VAR_STATS))  // CTR_TIMING diagnostic build: share of the waves' lifetime
     fprintf(stderr, "cutrace_amd timing (%% of wave cycles): cast_setup=%.1f planes=%.1f object_loop=%.1f tlas+aabb=%.1f "

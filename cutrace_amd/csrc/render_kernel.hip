@@ -99,7 +99,6 @@ constexpr int WG_THREADS = 64 * WAVES_PER_WG;
 
 struct V3 { float x, y, z; };
 typedef float float2_ __attribute__((ext_vector_type(2)));
-typedef float float4_ __attribute__((ext_vector_type(4)));
 // d = s * v.{lo|hi} - k.{lo|hi} for both halves of the SGPR pair s: v_pk_fma_f32 with op_sel choosing
 // which half of the VGPR pairs v and k is broadcast (vsel/ksel: 0 = low, 1 = high), k negated
 // d = s * v.{lo|hi} (both halves of the SGPR pair s times ONE broadcast half of the VGPR pair v)
@@ -146,20 +145,6 @@ __device__ __forceinline__ float slab_hi4(float ax, float bx, float ay, float by
   asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(ax), "v"(bx));
   asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(ay), "v"(by));
   asm("v_max_f32 %0, %1, %2" : "=v"(z) : "v"(az), "v"(bz));
-  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(mx));
-  return r;
-}
-// entry / exit distance of a box whose near and far plane per axis are already known (octant path: the wave's rays
-// share their direction signs): max(near distances, mn) / min(far distances, mx); a NaN operand drops out as above
-__device__ __forceinline__ float oct_lo4(float x, float y, float z, float mn) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(mn));
-  return r;
-}
-__device__ __forceinline__ float oct_hi4(float x, float y, float z, float mx) {
-  float r;
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(mx));
   return r;
@@ -263,7 +248,6 @@ struct KArgs {
   uint32_t frames;    // LDS stack frames per lane: the recursion depth that can be reached (bounces, or 1 when no
                       // material reflects or transmits: ray_color then never recurses)
   const CADDR uint32_t *order;  // dispatch slot -> wave (tile) index, or null = identity
-  uint32_t n_slots;             // dispatch slots of this launch: the number of waves, or more when the order pads (XCD bands)
   uint32_t *cost;               // per wave (tile): shader-clock ticks it took, or null
   // "Host delivery" (below): null group_done = the outputs are written in place
   float *host_depth, *host_color, *host_normal;
@@ -282,7 +266,14 @@ constexpr uint32_t GROUP_TILES = 64 / TW;
 #define CTR_CHEAP_FIRST_PCT 25u  // order_block_groups: share of the groups, the cheapest, dispatched before the dear ones
 #endif
 
-enum { M_RADIANCE = 0, M_SHADOW = 1, M_DONE = 2 };
+// What a lane casts its next ray for, and how deep its recursion stack is, share ONE register (a VGPR less to carry
+// through the cast loops): low 16 bits = stack depth; bit 31 = a shadow-loop cast, bit 30 = the pixel is finished,
+// neither = a radiance cast.  Every test is a single compare.
+constexpr uint32_t MSP_SHADOW = 0x80000000u, MSP_DONE = 0x40000000u;
+#define MSP_ACTIVE(m) ((int)(m) < 0x40000000)          /* radiance or shadow */
+#define MSP_IS_SHADOW(m) ((int)(m) < 0)
+#define MSP_IS_RADIANCE(m) ((uint32_t)(m) < 0x40000000u)
+#define MSP_DEPTH(m) ((int)((m) & 0xFFFFu))
 enum { ACT_NONE = 0, ACT_LIGHT = 1, ACT_BOUNCE = 2, ACT_UNWIND = 3 };
 
 template <uint32_t KV>
@@ -305,9 +296,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast,
   // and how many of the 64 lanes had a use for the wave-level work: [6] lanes whose ray meets one of the
   // visited node's child boxes, [7] lanes inside the leaf's box at a prefilter, [8] lanes in an exact test
-  // and what a walk by every lane for itself would take, in steps of the whole wave: per mesh entry the LARGEST number of
-  // [9] node visits and [10] triangle tests any one lane has a use for, [11] octant-path mesh entries
-  unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // and what a walk by every lane for itself would take, counted in steps of the whole wave: per mesh entry the LARGEST
+  // number of [9] node visits and [10] triangle tests any one lane has a use for (the bound on what a per-lane walk
+  // below some depth could save: DESIGN.md "Per-lane walk")
+  unsigned long long st[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef CTR_TIMING
   // diagnostic build only: shader-clock stamps per wave -> shards[4..13] = {cast setup, planes, object
   // loop, top-level walk + mesh AABB, mesh entry setup, BVH walk without leaves, leaves, radiance
@@ -331,7 +323,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   const uint32_t tiles_x = (w + TW - 1) / TW;
   const uint32_t tiles_y = (A.rows.n_rows + TH - 1) / TH;
   const uint32_t tiles_frame = tiles_x * tiles_y;
-  if (slot >= A.n_slots) return;  // whole wave exits together
+  if (slot >= tiles_frame * A.n_frames) return;  // whole wave exits together
   // Dispatch order.  Waves differ 10x in cost and the hardware hands them out in blockIdx order, so
   // with tiles in image order the last quarter of a frame is a tail of a few slow waves on an
   // otherwise empty GPU.  Every launch records what each tile cost; the next launch of the same
@@ -375,9 +367,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       out[3 * px_id + 2] = v.z;
     }
   };
+  // the lane's number from the hardware (two v_mbcnt) wherever a per-lane address is formed inside the loop: neither the
+  // lane id nor an address derived from it is then carried through the cast loops in a register
+  auto lane_now = [&]() -> uint32_t { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
   auto px_index = [&]() -> size_t {
-    uint32_t l = lane;
-    asm volatile("" : "+v"(l));  // recompute here: hoisted out of the loop the addresses would be spilled to scratch
+    const uint32_t l = lane_now();  // recomputed here: hoisted out of the loop the addresses would be spilled to scratch
     if (HOSTOUT) return (size_t)wave * 64u + l;  // tile-major staging ("Host delivery")
     return (size_t)frame * A.frame_stride_px + (size_t)(tile_px0 + (l / TW) * w + (l % TW));
   };
@@ -398,18 +392,28 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   const float ambient = cam.ambient;
 
   // ---- per-lane state machine ----
-  int mode = in_image ? M_RADIANCE : M_DONE;
+  uint32_t msp = in_image ? 0u : MSP_DONE;  // mode | stack depth (MSP_*); bounces left for the current activation = bounces - depth
   bool first_trip = true;   // wave-uniform: every in-image lane shades its primary hit in the first trip
   uint32_t wave_dbits = 0u; // wave-uniform: max finite depth bits of the tile (kernel.hpp:120-125)
   float min_t = A.fudge;
-  int sp = 0;               // stack depth; bounces left for the current activation = bounces - sp
   extern __shared__ float lds_stack[];
-  float *const stk = lds_stack + (size_t)wave_in_wg * A.frames * A.nf * 64 + lane;
-#define STK(frame, field) stk[((frame) * A.nf + (field)) * 64]
+#define STK(frame, field) (lds_stack + (size_t)wave_in_wg * A.frames * A.nf * 64 + lane_now())[((frame) * A.nf + (field)) * 64]
   V3 in_d = rd;             // direction of the radiance ray being shaded ("incoming"); its start is `ro` until the hit
   V3 nn = mk(0, 0, 0), pos = mk(0, 0, 0);  // (the hit point itself lives in `ro` from the hit on: it is
                                            //  the origin of every shadow ray of that hit)
   V3 in_dn = mk(0, 0, 0);   // incoming->dir.normalized() (shading.hpp:90,131; default_schema.hpp:245)
+  // PARK (the 6-waves-per-SIMD build): five dwords of shading state that no cast reads — in_dn and two components of
+  // nn, written once per shaded hit, read once per light — live in LDS behind the wave's stack instead of in VGPRs.
+  // They are what the register allocator spilled to scratch at 80 VGPRs (write-back traffic all frame long: 1.9x the
+  // compulsory bytes on the bunny frame, 3.5x with 64 000 triangles); five, because LDS is handed out in 1280-byte
+  // granules and 5 KB of stack (bounces 5) + 1280 B is the most that still lets 24 waves share a CU
+  // (profiles/r03/lds_granule.txt).
+  constexpr bool PARK = (KV & KV_OCC6) != 0;
+#define PRK(i) (lds_stack + (size_t)WAVES_PER_WG * A.frames * A.nf * 64 + (size_t)wave_in_wg * 5 * 64 + lane_now())[(i) * 64]
+  auto set_in_dn = [&](V3 v) { if (PARK) { PRK(0) = v.x; PRK(1) = v.y; PRK(2) = v.z; } else in_dn = v; };
+  auto get_in_dn = [&]() -> V3 { return PARK ? mk(PRK(0), PRK(1), PRK(2)) : in_dn; };
+  auto set_nn = [&](V3 v) { if (PARK) { PRK(3) = v.x; PRK(4) = v.y; nn.z = v.z; } else nn = v; };
+  auto get_nn = [&]() -> V3 { return PARK ? mk(PRK(3), PRK(4), nn.z) : nn; };
   V3 fin = mk(0, 0, 0);     // phong accumulator ("final")
   float light_dist = 0.f, intensity = 0.f;
   uint32_t mat_i = 0, li = 0;
@@ -424,11 +428,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   // back by v_readlane (a half-rate VALU instruction per dword, every trip); an s_load from the scalar cache costs
   // no VALU slot.  The pointer is made opaque once per trip so that the loads stay inside the trip.
   const CADDR KArgs *AK = (const CADDR KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-  while (BALLOT(mode != M_DONE) != 0ull) {
+  while (BALLOT(MSP_ACTIVE(msp)) != 0ull) {
     asm volatile("" : "+s"(AK));
     TSTAMP(t_trip0);
-    const bool active = mode != M_DONE;
-    const bool shadow_cast = mode == M_SHADOW;
+    const bool active = MSP_ACTIVE(msp);
+    const bool shadow_cast = MSP_IS_SHADOW(msp);
     n_casts += (unsigned long long)__builtin_popcountll(BALLOT(active));
     if (STATS) { st[0]++; st[5] += __builtin_popcountll(BALLOT(active)); }
 
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.x), t_lead) >> 31) |
                (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.y), t_lead) >> 31) << 1) |
                (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.z), t_lead) >> 31) << 2)) ^
-              ((ANYHIT && (uint32_t)__builtin_amdgcn_readlane(mode, t_lead) == (uint32_t)M_SHADOW) ? 7u : 0u);
+              ((ANYHIT && ((uint32_t)__builtin_amdgcn_readlane((int)msp, t_lead) >> 31) != 0u) ? 7u : 0u);
           while (t_pend != TL_NONE && !(t_pend & BVH_LEAF_FLAG)) {
             const CADDR DNode &N = A.nodes[AK->tlas_begin + t_pend];
             auto t_hits = [&](int c) -> mask_t {
@@ -807,38 +811,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                 const float third = absa - (sA1 + sA2);
                 asm("v_min3_f32 %0, %1, %2, %3" : "=v"(slack) : "v"(sA1), "v"(sA2), "v"(third));
               }
-              mask_t rej = FCMP(slack, -E, FC_OLT);
-#ifdef CTR_EXP_PF2
-              {  // diagnostic: the first prefilter stage a second time (ray direction made opaque: no merging)
-                float rx = rd.x, ry = rd.y, rz = rd.z;
-                PIN3(rx, ry, rz);
-                const float alpha2 = __builtin_fmaf(rx, T.nx, __builtin_fmaf(ry, T.ny, rz * T.nz));
-                float2_ q2_xy, q2_z;
-                q2_xy.x = __builtin_fmaf(dy, rz, -(dz * ry));
-                q2_xy.y = __builtin_fmaf(dz, rx, -(dx * rz));
-                q2_z.x = __builtin_fmaf(dx, ry, -(dy * rx));
-                q2_z.y = 0.0f;
-                float2_ m2;
-                PKMULB(m2, ldpair(T.ab[0]), q2_xy, 0);
-                PKFMAB(m2, ldpair(T.ab[1]), q2_xy, 1, m2);
-                PKFMAB(m2, ldpair(T.ab[2]), q2_z, 0, m2);
-                const uint32_t sgn2 = __float_as_uint(alpha2) & 0x80000000u;
-                float2_ s2;
-                s2.x = __uint_as_float(sgn2 | 0x3f800000u);
-                s2.y = 0.0f;
-                float2_ sm2;
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(sm2) : "v"(m2), "v"(s2));
-                const float absa2 = fabsf(alpha2);
-                float dmax2 = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-                asm volatile("" : "+v"(dmax2));
-                const uint32_t e_a2 = __float_as_uint(dmax2 * T.ke), e_b2 = __float_as_uint(T.ke2);
-                const float E2 = __uint_as_float(e_a2 > e_b2 ? e_a2 : e_b2) * cmax;
-                float slack2;
-                const float third2 = absa2 - (sm2.y + sm2.x);
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(slack2) : "v"(sm2.y), "v"(sm2.x), "v"(third2));
-                rej &= FCMP(slack2, -E2, FC_OLT);
-              }
-#endif
+              const mask_t rej = FCMP(slack, -E, FC_OLT);
               flat_m = FCMP(absa, E, FC_OLE);  // alpha within rounding of 0: always a candidate
               c_m = lanes_m & (~rej | flat_m);
               if (c_m == 0ull) return;
@@ -968,119 +941,29 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             // 64 000-triangle mesh -8 % against near-to-far for both; profiles/r02/traversal_order.txt).
             // (only where a shadow cast stops at its first occluder; the ordered shadow loop of scenes with transparent
             //  materials is a nearest-hit cast)
-            const uint32_t lead_shadow = (ANYHIT && (uint32_t)__builtin_amdgcn_readlane(mode, lead) == (uint32_t)M_SHADOW) ? 7u : 0u;
+            const uint32_t lead_shadow = (ANYHIT && ((uint32_t)__builtin_amdgcn_readlane((int)msp, lead) >> 31) != 0u) ? 7u : 0u;
             const uint32_t neg_bits = lead_shadow ^ (nb_x | (nb_y << 1) | (nb_z << 2));
             // the nine per-ray constants of the box test, two to a register pair; PKFMA picks the half it
             // needs with op_sel, so packing costs no extra registers
-            // Octant path.  A slab's entry distance is min(t1, t2) and its exit max(t1, t2) only because a lane does not
-            // know its ray's direction sign at compile time; which of the two it is, is the sign of the reciprocal.  When
-            // every lane that needs the mesh has the SAME signs (coherent rays: nearly always) the choice is wave-uniform:
-            // the node's near and far planes are picked by the OFFSET they are loaded from (lo or hi, per axis), the
-            // per-ray constants are swapped to match once per mesh entry, and a box costs max3 + max, min3 + min and one
-            // compare instead of three min, three max on top of them (24 of a node visit's ~70 vector instructions).
-            // t1 <= t2 holds exactly (monotonic rounding of the FMAs; lo <= hi, ka >= kb for a positive reciprocal), so
-            // both forms give the same lane masks.  A wave with mixed signs takes the min/max form below.
-#ifndef CTR_NO_OCT
-            const mask_t ng_x = FCMP(ria.x, 0.0f, FC_OLT) & bb_m, ng_y = FCMP(ria.y, 0.0f, FC_OLT) & bb_m,
-                         ng_z = FCMP(ria.z, 0.0f, FC_OLT) & bb_m;
-            const bool oct_ok = (ng_x == 0ull || ng_x == bb_m) && (ng_y == 0ull || ng_y == bb_m) && (ng_z == 0ull || ng_z == bb_m);
-            const bool sw_x = oct_ok && ng_x != 0ull, sw_y = oct_ok && ng_y != 0ull, sw_z = oct_ok && ng_z != 0ull;
-            if (STATS && oct_ok) st[11]++;
-#else
-            const bool oct_ok = false, sw_x = false, sw_y = false, sw_z = false;
-#endif
-            // byte offsets inside a DNode4 of the planes multiplied first (k1) and second (k2) on each axis: (lo, hi), or
-            // (hi, lo) on an axis the whole wave looks down
-            const uint32_t o1x = sw_x ? 48u : 0u, o1y = sw_y ? 64u : 16u, o1z = sw_z ? 80u : 32u;
-            const uint32_t o2x = sw_x ? 0u : 48u, o2y = sw_y ? 16u : 64u, o2z = sw_z ? 32u : 80u;
-            const V3 k1 = mk(sw_x ? kb.x : ka.x, sw_y ? kb.y : ka.y, sw_z ? kb.z : ka.z);
-            const V3 k2 = mk(sw_x ? ka.x : kb.x, sw_y ? ka.y : kb.y, sw_z ? ka.z : kb.z);
-            const float2_ c_rxy = {ria.x, ria.y}, c_rzk = {ria.z, k1.x}, c_kyz = {k1.y, k1.z};
-            const float2_ c_bxy = {k2.x, k2.y}, c_bz = {k2.z, 0.0f};
+            const float2_ c_rxy = {ria.x, ria.y}, c_rzk = {ria.z, ka.x}, c_kyz = {ka.y, ka.z};
+            const float2_ c_bxy = {kb.x, kb.y}, c_bz = {kb.z, 0.0f};
             // children (c, c+1) of one node: six v_pk_fma_f32 give the six slab distances of both boxes;
             // a lane takes a child unless it misses for certain: max(entry, min_t) > min(exit, lim)
             // (v_min/v_max drop a NaN operand, a NaN that survives compares false -> entered)
-            // the planes of the four children, one SGPR quad per axis and side, loaded from the offsets chosen above
-            // (s_load_dwordx4 with an SGPR offset: written out, because the compiler turns a variable offset into an
-            // address computation and a wait per pair)
-            // (the child descriptors and the order axis travel in the same batch of loads, one wait for all)
-            typedef uint32_t uint4_ __attribute__((ext_vector_type(4)));
-            auto box_hits4 = [&](const CADDR DNode4 *np, mask_t &h0, mask_t &h1, mask_t &h2, mask_t &h3, uint4_ &kids, uint32_t &axis) {
-              float4_ P1x, P1y, P1z, P2x, P2y, P2z;
-              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1x) : "s"(np), "s"(o1x));
-              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1y) : "s"(np), "s"(o1y));
-              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1z) : "s"(np), "s"(o1z));
-              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2x) : "s"(np), "s"(o2x));
-              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2y) : "s"(np), "s"(o2y));
-              asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2z) : "s"(np), "s"(o2z));
-              asm volatile("s_load_dwordx4 %0, %1, 0x60" : "=&s"(kids) : "s"(np));
-              asm volatile("s_load_dword %0, %1, 0x70" : "=&s"(axis) : "s"(np));
-              asm volatile("s_waitcnt lgkmcnt(0)"
-                           : "+s"(P1x), "+s"(P1y), "+s"(P1z), "+s"(P2x), "+s"(P2y), "+s"(P2z), "+s"(kids), "+s"(axis));
-#ifdef CTR_EXP_NLOAD2
-              // diagnostic: the node's load round trip a second time (dependent on the first through the order axis)
-              {
-                const CADDR DNode4 *np2 = np + (axis >> 8);  // axis < 3: the same node
-                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1x) : "s"(np2), "s"(o1x));
-                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1y) : "s"(np2), "s"(o1y));
-                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P1z) : "s"(np2), "s"(o1z));
-                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2x) : "s"(np2), "s"(o2x));
-                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2y) : "s"(np2), "s"(o2y));
-                asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(P2z) : "s"(np2), "s"(o2z));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(P1x), "+s"(P1y), "+s"(P1z), "+s"(P2x), "+s"(P2y), "+s"(P2z));
-              }
-#endif
-#define CTR_PAIR_T(SEL0, SEL1)                                                       \
-  float2_ t1x, t1y, t1z, t2x, t2y, t2z;                                              \
-  PKFMA(t1x, __builtin_shufflevector(P1x, P1x, SEL0, SEL1), c_rxy, 0, c_rzk, 1);     \
-  PKFMA(t1y, __builtin_shufflevector(P1y, P1y, SEL0, SEL1), c_rxy, 1, c_kyz, 0);     \
-  PKFMA(t1z, __builtin_shufflevector(P1z, P1z, SEL0, SEL1), c_rzk, 0, c_kyz, 1);     \
-  PKFMA(t2x, __builtin_shufflevector(P2x, P2x, SEL0, SEL1), c_rxy, 0, c_bxy, 0);     \
-  PKFMA(t2y, __builtin_shufflevector(P2y, P2y, SEL0, SEL1), c_rxy, 1, c_bxy, 1);     \
-  PKFMA(t2z, __builtin_shufflevector(P2z, P2z, SEL0, SEL1), c_rzk, 0, c_bz, 0);
-#define CTR_PAIR_OCT(SEL0, SEL1, ha, hb)                                             \
-  {                                                                                  \
-    CTR_PAIR_T(SEL0, SEL1)                                                           \
-    const float lo_a = oct_lo4(t1x.x, t1y.x, t1z.x, min_t), hi_a = oct_hi4(t2x.x, t2y.x, t2z.x, lim); \
-    const float lo_b = oct_lo4(t1x.y, t1y.y, t1z.y, min_t), hi_b = oct_hi4(t2x.y, t2y.y, t2z.y, lim); \
-    ha = bb_m & ~FCMP(lo_a, hi_a, FC_OGT);                                           \
-    hb = bb_m & ~FCMP(lo_b, hi_b, FC_OGT);                                           \
-  }
-#define CTR_PAIR_MM(SEL0, SEL1, ha, hb)                                              \
-  {                                                                                  \
-    CTR_PAIR_T(SEL0, SEL1)                                                           \
-    const float lo_a = slab_lo4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, min_t);    \
-    const float hi_a = slab_hi4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, lim);      \
-    const float lo_b = slab_lo4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, min_t);    \
-    const float hi_b = slab_hi4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, lim);      \
-    ha = bb_m & ~FCMP(lo_a, hi_a, FC_OGT);                                           \
-    hb = bb_m & ~FCMP(lo_b, hi_b, FC_OGT);                                           \
-  }
-              if (oct_ok) {
-                CTR_PAIR_OCT(0, 1, h0, h1)
-                CTR_PAIR_OCT(2, 3, h2, h3)
-              } else {
-                CTR_PAIR_MM(0, 1, h0, h1)
-                CTR_PAIR_MM(2, 3, h2, h3)
-              }
-#ifdef CTR_EXP_BOX2
-              // diagnostic: the box arithmetic a second time (operands made opaque so that it is not merged with the first)
-              {
-                mask_t x0, x1, x2, x3;
-                asm volatile("" : "+s"(P1x), "+s"(P1y), "+s"(P1z), "+s"(P2x), "+s"(P2y), "+s"(P2z));
-                if (oct_ok) {
-                  CTR_PAIR_OCT(0, 1, x0, x1)
-                  CTR_PAIR_OCT(2, 3, x2, x3)
-                } else {
-                  CTR_PAIR_MM(0, 1, x0, x1)
-                  CTR_PAIR_MM(2, 3, x2, x3)
-                }
-                h0 &= x0; h1 &= x1; h2 &= x2; h3 &= x3;
-              }
-#endif
-#undef CTR_PAIR_T
-#undef CTR_PAIR_OCT
-#undef CTR_PAIR_MM
+            auto box_hits2 = [&](const CADDR DNode4 &N, int c, mask_t &ha, mask_t &hb) {
+              float2_ t1x, t1y, t1z, t2x, t2y, t2z;
+              PKFMA(t1x, ldpair2(&N.lo[0][c]), c_rxy, 0, c_rzk, 1);
+              PKFMA(t1y, ldpair2(&N.lo[1][c]), c_rxy, 1, c_kyz, 0);
+              PKFMA(t1z, ldpair2(&N.lo[2][c]), c_rzk, 0, c_kyz, 1);
+              PKFMA(t2x, ldpair2(&N.hi[0][c]), c_rxy, 0, c_bxy, 0);
+              PKFMA(t2y, ldpair2(&N.hi[1][c]), c_rxy, 1, c_bxy, 1);
+              PKFMA(t2z, ldpair2(&N.hi[2][c]), c_rzk, 0, c_bz, 0);
+              const float lo_a = slab_lo4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, min_t);
+              const float hi_a = slab_hi4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, lim);
+              const float lo_b = slab_lo4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, min_t);
+              const float hi_b = slab_hi4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, lim);
+              ha = bb_m & ~FCMP(lo_a, hi_a, FC_OGT);
+              hb = bb_m & ~FCMP(lo_b, hi_b, FC_OGT);
             };
             auto leaf = [&](uint32_t desc, mask_t lanes) {
               TSTAMP(t_leaf0);
@@ -1112,15 +995,15 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 #endif
             for (;;) {
               if (STATS) st[1]++;
+              const CADDR DNode4 &N = nodes4[cur];
               mask_t h0, h1, h2, h3;
-              uint4_ kids;
-              uint32_t n_axis;
-              box_hits4(&nodes4[cur], h0, h1, h2, h3, kids, n_axis);
+              box_hits2(N, 0, h0, h1);
+              box_hits2(N, 2, h2, h3);
               if (STATS) { st[6] += __builtin_popcountll(h0 | h1 | h2 | h3); pl_nodes += INVB(h0 | h1 | h2 | h3) ? 1u : 0u; }
-              const uint32_t d0 = kids.x, d1 = kids.y, d2 = kids.z, d3 = kids.w;
+              const uint32_t d0 = N.child[0], d1 = N.child[1], d2 = N.child[2], d3 = N.child[3];
               // children are stored sorted along the node's order axis; a wave whose lead ray points the other
               // way takes them in reverse (wave-uniform selects): e0/g0 = nearest ... e3/g3 = farthest
-              const bool rev = ((neg_bits >> n_axis) & 1u) != 0u;
+              const bool rev = ((neg_bits >> N.axis) & 1u) != 0u;
               const uint32_t e0 = rev ? d3 : d0, e1 = rev ? d2 : d1, e2 = rev ? d1 : d2, e3 = rev ? d0 : d3;
               const mask_t g0 = rev ? h3 : h0, g1 = rev ? h2 : h1, g2 = rev ? h1 : h2, g3 = rev ? h0 : h3;
               // ONE pass, farthest child first: a hit leaf is tested at once; a hit inner child becomes the node to
@@ -1203,18 +1086,20 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     // =====================================================================
     int act = ACT_NONE;
     float first_depth = 0.f;  // primary-hit depth of this lane, alive in the first trip only
-    if (mode == M_RADIANCE) {
+    if (MSP_IS_RADIANCE(msp)) {
       // ---- hit record: hit point, normal (per primitive), material ----
       V3 normal = mk(0, 0, 0);
       if (was_hit) {
         const CADDR DObj &H = AK->objs[bobj];
         mat_i = H.mat;
         pos = vadd(ro, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
-        { float unused_n; in_dn = vnormalized_n(in_d, unused_n); }
+        float unused_n0;
+        const V3 hit_dn = vnormalized_n(in_d, unused_n0);
+        set_in_dn(hit_dn);
         const uint32_t ht = H.type;
         if (ht == CTR_OBJ_SPHERE) {
           // default_schema.hpp:245-246: hit uses the NORMALIZED direction
-          const V3 hit = vadd(ro, vscale(in_dn, best));
+          const V3 hit = vadd(ro, vscale(hit_dn, best));
           normal = vnormalized(vsub(hit, mk(H.f[0], H.f[1], H.f[2])));
           ro = hit;
         } else if (ht == CTR_OBJ_PLANE) {
@@ -1240,11 +1125,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         // phong prologue, shading.hpp:66-76
         const CADDR DMat &M = AK->mats[mat_i];
         fin = vscale(mk(M.cx, M.cy, M.cz), ambient);
-        { float unused_n; nn = vnormalized_n(normal, unused_n); }
+        { float unused_n; set_nn(vnormalized_n(normal, unused_n)); }
         li = 0;
         act = ACT_LIGHT;
       }
-    } else if (mode == M_SHADOW) {
+    } else if (MSP_IS_SHADOW(msp)) {
       // ---- one iteration of shadow_intensity's loop, shading.hpp:32-42 ----
       bool done_shadow;
       float shadow_fac = 0.f;
@@ -1270,13 +1155,14 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           const V3 specular = vscale(diffuse, M.specular);  // default_schema.hpp:328
           const V3 color = mk(Lg.cx, Lg.cy, Lg.cz);
           const V3 nd = rd;  // the shadow ray's direction IS the normalized direction to the light
-          const float fd = smax(0.0f, vdot(nn, nd));
+          const V3 nn_ = get_nn();
+          const float fd = smax(0.0f, vdot(nn_, nd));
           const V3 ld = vmul(diffuse, color);
-          const V3 hsum = vadd(vscale(in_dn, -1.0f), nd);
+          const V3 hsum = vadd(vscale(get_in_dn(), -1.0f), nd);
           // the half vector feeds only the specular colour term: with the fast specular path its
           // normalisation uses the 1-ulp v_rsq_f32 instead of IEEE sqrt + division
           const V3 hv = FASTPOW ? vscale(hsum, __builtin_amdgcn_rsqf(vdot(hsum, hsum))) : vnormalized(hsum);
-          const float sx = smax(0.0f, vdot(nn, hv));
+          const float sx = smax(0.0f, vdot(nn_, hv));
           float fs;
           if (FASTPOW) {
             // exp2(e*log2(x)) on the f32 transcendental pipe: relative error ~1e-6 wherever the
@@ -1313,7 +1199,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         light_dist = distance * dir_norm;
         intensity = 0.0f;
         min_t = (float)(0.0 + 1e-3);  // last_hit = 0
-        mode = M_SHADOW;
+        msp |= MSP_SHADOW;
       } else {
         act = ACT_BOUNCE;  // phong returned `fin`
       }
@@ -1323,6 +1209,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       // shading.hpp:126-150 with rgb = fin
       const CADDR DMat &M = AK->mats[mat_i];
       const float reflective = M.reflexivity, translucent = M.transparency;
+      const int sp = MSP_DEPTH(msp);
       const bool more = sp < AK->bounces;  // `if constexpr (bounces != 0)`
       const bool do_refl = more && (double)reflective >= 1e-6;
       const bool do_trans = more && (double)translucent >= 1e-6;
@@ -1333,14 +1220,14 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           STK(sp, F_PX) = pos.x; STK(sp, F_PY) = pos.y; STK(sp, F_PZ) = pos.z;
           STK(sp, F_DX) = in_d.x; STK(sp, F_DY) = in_d.y; STK(sp, F_DZ) = in_d.z;
         }
-        sp++;
+        msp = (uint32_t)(sp + 1);  // one frame deeper, a radiance cast
         if (do_refl) {
           // reflect(nd, nn) = nd - (2*(nn.nd))*nn, vector.hpp:204-206
-          in_d = vsub(in_dn, vscale(nn, 2.0f * vdot(nn, in_dn)));
+          const V3 nn_ = get_nn(), dn_ = get_in_dn();
+          in_d = vsub(dn_, vscale(nn_, 2.0f * vdot(nn_, dn_)));
         }
         ro = pos; rd = in_d;
         min_t = A.fudge;
-        mode = M_RADIANCE;
       } else {
         out_rgb = fin;
         act = ACT_UNWIND;
@@ -1349,11 +1236,12 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 
     if (act == ACT_UNWIND) {
       // return `out_rgb` to the suspended callers
+      int sp = MSP_DEPTH(msp);
       for (;;) {
         if (sp == 0) {
           const size_t px_id = px_index();
           store3(color_out, px_id, out_rgb);
-          mode = M_DONE;
+          msp = MSP_DONE;
           break;
         }
         --sp;
@@ -1369,9 +1257,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             in_d = mk(STK(sp, F_DX), STK(sp, F_DY), STK(sp, F_DZ));
             ro = mk(STK(sp, F_PX), STK(sp, F_PY), STK(sp, F_PZ));
             rd = in_d;
-            sp++;
+            msp = (uint32_t)(sp + 1);  // the frame stays; a radiance cast
             min_t = A.fudge;
-            mode = M_RADIANCE;
             break;
           }
           out_rgb = rgb;
@@ -1395,6 +1282,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     TACC(8, t_cont_mid, t_cont1);
   }
 #undef STK
+#undef PRK
 
   // (the tile's cost for the next launch's order ends here: what the group copy below costs the one wave that makes
   //  it depends on the link, not on the tile)
@@ -1496,7 +1384,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     }
     unsigned long long *sh = counters + (size_t)(wave % CTR_SHARDS) * CTR_SHARD_WORDS;
     if (STATS && lane == 0) {
-      for (int q = 0; q < 12; q++) atomicAdd(&sh[4 + q], st[q]);
+      for (int q = 0; q < 11; q++) atomicAdd(&sh[4 + q], st[q]);
     }
 #ifdef CTR_TIMING
     if (lane == 0) {
@@ -1514,9 +1402,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 
 // ---- after_render: block 0 folds the counter shards, block 1 builds the next dispatch order ----
 // block of CTR_SHARDS threads: thread t owns shard t; wave-level reduction, then one LDS atomic per
-// wave and word; adds into out[0..13] (max for word 1) and zeroes the shards for the next launch
+// wave and word; adds into out[0..14] (max for word 1) and zeroes the shards for the next launch
 __device__ void fold_block(unsigned long long *__restrict__ shards, unsigned long long *__restrict__ out) {
-  constexpr int NW = 16;
+  constexpr int NW = 15;
   __shared__ unsigned long long acc[NW];
   if (threadIdx.x < NW) acc[threadIdx.x] = 0ull;
   __syncthreads();
@@ -1786,7 +1674,6 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.nf = L.need_cold_frames ? 10u : 4u;
   A.frames = (uint32_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1);
   A.order = (const CADDR uint32_t *)L.order;
-  A.n_slots = (L.order && L.order_slots) ? L.order_slots : (uint32_t)launch_waves(L);
   A.cost = L.cost;
   const bool host_delivery = (KV & KV_HOSTOUT) != 0;
   if (host_delivery != (L.group_done != nullptr)) return (int)hipErrorInvalidValue;
@@ -1796,12 +1683,13 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.host_normal = L.host_normal;
   A.group_done = L.group_done;
   size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
+  if (KV & KV_OCC6) lds_bytes += (size_t)WAVES_PER_WG * 5 * 64 * sizeof(float);  // PARK
   // diagnostic only: extra dynamic LDS per workgroup caps the waves resident per CU (occupancy sweeps)
   if (const char *pad = getenv("CUTRACE_LDS_PAD")) lds_bytes += (size_t)atol(pad);
   const uint64_t waves = launch_waves(L);
   if (waves > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
   if (waves == 0) return 0;
-  const uint32_t grid = (uint32_t)(((uint64_t)A.n_slots + WAVES_PER_WG - 1) / WAVES_PER_WG);
+  const uint32_t grid = (uint32_t)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
   // counters go through the scene's shard buffer and are folded into the caller's words afterwards
   unsigned long long *shards = L.counters ? L.shards : nullptr;
   if (L.order_init && L.order) {
@@ -1878,6 +1766,10 @@ uint64_t ctr_staging_groups(const RenderLaunch &L) {
   return ((tiles_x + GROUP_TILES - 1) / GROUP_TILES) * tiles_y;
 }
 
+// The 6-waves-per-SIMD build parks 1280 bytes of shading state per wave in LDS (render_kernel PARK); LDS is handed out
+// in granules of 1280 bytes (160 KB / 128), and 24 waves per CU need at most 5 granules each
+static bool occ6_fits(size_t stack_bytes) { return (stack_bytes + 1280u + 1279u) / 1280u <= 5u; }
+
 // Host delivery exists for the variants ctr_api.cpp picks by itself (not for the ablation / diagnostic builds)
 bool ctr_host_delivery_available(uint32_t variant) {
   constexpr uint32_t DEF = KV_PREFILTER | KV_BVH | KV_FASTPOW;
@@ -1891,7 +1783,7 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
     constexpr uint32_t DEF = KV_PREFILTER | KV_BVH | KV_FASTPOW | KV_HOSTOUT;
     const size_t sb = (size_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1) * (L.need_cold_frames ? 10u : 4u) * 64 * sizeof(float);
     if (!(L.variant & KV_ANYHIT)) return launch<DEF>(L, s);
-    if ((L.variant & KV_OCC6) && sb * 24 <= 160u * 1024u) return launch<DEF | KV_ANYHIT | KV_OCC6>(L, s);
+    if ((L.variant & KV_OCC6) && occ6_fits(sb)) return launch<DEF | KV_ANYHIT | KV_OCC6>(L, s);
     return launch<DEF | KV_ANYHIT>(L, s);
   }
   if (L.variant & KV_COUNT) return launch<KV_PREFILTER | KV_COUNT>(L, s);
@@ -1903,7 +1795,7 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
   // wave mostly waits for L2 (ctr_api.cpp picks it by triangle count); only the shipped default variant has it
   // (and only when 24 waves' recursion stacks fit the CU's 160 KB of LDS: bounces <= 6 without cold frames)
   const size_t stack_bytes = (size_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1) * (L.need_cold_frames ? 10u : 4u) * 64 * sizeof(float);
-  if ((L.variant & KV_OCC6) && stack_bytes * 24 <= 160u * 1024u &&
+  if ((L.variant & KV_OCC6) && occ6_fits(stack_bytes) &&
       (L.variant & (KV_PREFILTER | KV_ANYHIT | KV_BVH | KV_FASTPOW)) == (KV_PREFILTER | KV_ANYHIT | KV_BVH | KV_FASTPOW))
     return launch<KV_OCC6 | KV_PREFILTER | KV_ANYHIT | KV_BVH | KV_FASTPOW>(L, s);
   return (L.variant & KV_FASTPOW) ? launch_main<KV_FASTPOW>(L, s) : launch_main<0>(L, s);

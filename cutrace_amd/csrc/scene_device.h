@@ -149,8 +149,6 @@ struct RenderLaunch {
   uint32_t variant;
   // tile scheduling (render_kernel.hip "Dispatch order"): all three may be null
   const uint32_t *order;  // dispatch slot -> wave index for THIS launch (a permutation of 0..waves-1)
-  uint32_t order_slots;   // entries of `order` when it holds more than one per wave (padding entries >= the number of
-                          // waves start a wave that exits at once: XCD bands, ctr_api.cpp), 0 = one per wave
   uint32_t *cost;         // out: per-wave cost of this launch
   uint32_t *order_next;   // out (or null = keep the old order): waves sorted by descending cost
                           // (may alias `order`: written after the render)
