@@ -80,6 +80,32 @@ extern "C" __device__ uint32_t ctr_writelane(uint32_t value, uint32_t lane, uint
 
 namespace {
 
+#if defined(CTR_PROFILE)
+__device__ unsigned int g_prof[128];  // executions of the CTR_MARK segments, summed over the waves of every launch
+#endif
+
+// ---- execution profile of the source's straight-line segments (scripts/dynamic_mix.py) ----
+// CTR_MARK(n) opens segment n.  -DCTR_MARKS: a comment in the ISA, from which the segment's instructions are counted;
+// -DCTR_PROFILE: a counter of how often a wave runs the segment — one global atomic add by lane 0 with EXEC forced
+// to that lane and restored, so a segment inside divergent code counts once per wave that reaches it, whichever
+// lanes are live; otherwise nothing.
+#if defined(CTR_PROFILE)
+#define CTR_MARK(n)                                                                                                    \
+do {                                                                                                                 \
+  unsigned long long pm_x;                                                                                           \
+  uint32_t pm_a, pm_b;                                                                                               \
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 1\n\t"                    \
+               "global_atomic_add %1, %2, %3 offset:%4\n\ts_mov_b64 exec, %0"                                         \
+               : "=&s"(pm_x), "=&v"(pm_a), "=&v"(pm_b)                                                               \
+               : "s"(g_prof), "n"(4 * (n))                                                                        \
+               : "memory");                                                                                          \
+} while (0)
+#elif defined(CTR_MARKS)
+#define CTR_MARK(n) asm volatile("; CTR_MARK %0" ::"n"(n))
+#else
+#define CTR_MARK(n)
+#endif
+
 #ifndef CTR_TW
 #define CTR_TW 8
 #endif
@@ -99,6 +125,8 @@ constexpr int WG_THREADS = 64 * WAVES_PER_WG;
 
 struct V3 { float x, y, z; };
 typedef float float2_ __attribute__((ext_vector_type(2)));
+template <int N> struct SiteTag { static constexpr int value = N; };  // which inlined copy of a lambda (CTR_MARK ids)
+#define SITE(n) SiteTag<n>()
 // d = s * v.{lo|hi} - k.{lo|hi} for both halves of the SGPR pair s: v_pk_fma_f32 with op_sel choosing
 // which half of the VGPR pairs v and k is broadcast (vsel/ksel: 0 = low, 1 = high), k negated
 // d = s * v.{lo|hi} (both halves of the SGPR pair s times ONE broadcast half of the VGPR pair v)
@@ -176,10 +204,12 @@ __device__ __forceinline__ V3 vnormalized(V3 a) { return vscale(a, 1.0f / vnorm(
 // vector, inf, NaN): the whole wave takes the library path.
 __device__ __forceinline__ void norm_and_inverse(float x, float &n, float &inv) {
   if (BALLOT(!(x >= 0x1p-80f && x <= 0x1p80f)) != 0ull) {
+    CTR_MARK(90);  // library square root and division
     n = sqrtf(x);
     inv = 1.0f / n;
     return;
   }
+  CTR_MARK(91);
   const float s0 = __builtin_amdgcn_sqrtf(x);
   const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
   const float rm = __builtin_fmaf(-sm, s0, x), rp = __builtin_fmaf(-sp, s0, x);
@@ -316,6 +346,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 #ifdef CTR_WAVELOG
   const unsigned long long wl_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
 #endif
+  CTR_MARK(0);  // wave prologue
   const uint32_t w = A.w, h = A.h;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
@@ -431,6 +462,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   while (BALLOT(MSP_ACTIVE(msp)) != 0ull) {
     asm volatile("" : "+s"(AK));
     TSTAMP(t_trip0);
+    CTR_MARK(1);  // trip head: cast set-up
     const bool active = MSP_ACTIVE(msp);
     const bool shadow_cast = MSP_IS_SHADOW(msp);
     n_casts += (unsigned long long)__builtin_popcountll(BALLOT(active));
@@ -448,6 +480,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     float ria_big = 0.f;
     float cmax = 0.f;
     if (AK->has_mesh) {
+      CTR_MARK(2);
       // 1-ulp reciprocals, clamped to +-1e30: an axis-parallel ray (d = 0 -> inf) then gives huge
       // FINITE slab distances with the right signs instead of inf - inf = NaN
       ria = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(rd.x), -1e30f), 1e30f),
@@ -459,6 +492,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 
     TSTAMP(t_loop0);
     TACC(0, t_trip0, t_loop0);
+    CTR_MARK(3);  // planes: set-up
     typedef unsigned long long mask_t;
     const bool anyhit_cast = ANYHIT && shadow_cast;
     // ---- planes: plane::intersect, default_schema.hpp:189-201, all in lane masks ----
@@ -479,7 +513,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       float tiny = 1e-37f;
       asm volatile("" : "+v"(tiny));  // keep it in a VGPR: a literal operand would halve the FMA's issue rate
       // one plane against the lanes in need_m; returns false when every lane has retired (any-hit)
-      auto plane_exact = [&](uint32_t pidx, float num, float den, mask_t need_m) -> bool {
+      auto plane_exact = [&](uint32_t pidx, float num, float den, mask_t need_m, auto site) -> bool {
+        CTR_MARK(110 + decltype(site)::value);  // a plane some lane needs the quotient of
         bool retire = false;
         if (INVB(need_m)) {
           const float t0 = num / den;
@@ -499,13 +534,14 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         }
         return true;
       };
-      auto plane_test = [&](uint32_t pidx, float num, float den) -> bool {
+      auto plane_test = [&](uint32_t pidx, float num, float den, auto site) -> bool {  // (site: which inlined copy, for CTR_MARK)
+        CTR_MARK(100 + decltype(site)::value);  // one plane's classification
         const float nump = __uint_as_float(__float_as_uint(num) ^ (__float_as_uint(den) & 0x80000000u));
         const float denp = fabsf(den);
         const mask_t need_m = live_m & ~(FCMP(nump, __builtin_fmaf(mt_lo, denp, -tiny), FC_OLT) |
                                          FCMP(nump, __builtin_fmaf(lhv, denp, tiny), FC_OGT));
         if (need_m == 0ull) return true;
-        return plane_exact(pidx, num, den, need_m);
+        return plane_exact(pidx, num, den, need_m, site);
       };
       // Two planes per 64-byte record with interleaved coordinates: the numerators (point - origin).normal
       // and denominators dir.normal of BOTH planes come from packed f32 multiplies and adds — the
@@ -523,6 +559,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       const uint32_t n_pairs = (AK->n_planes + 1u) >> 1;
       for (uint32_t p = 0; p < n_pairs;) {
         if (n_pairs - p >= 3u) {
+          CTR_MARK(6);  // three plane records
           const CADDR DPlanePair &P0 = AK->planes[p], &P1 = AK->planes[p + 1], &P2 = AK->planes[p + 2];
           float2_ num0, den0, num1, den1, num2, den2;
           num_den(P0, num0, den0);
@@ -531,23 +568,24 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           const uint32_t i00 = P0.index[0], i01 = P0.index[1], i10 = P1.index[0], i11 = P1.index[1], i20 = P2.index[0],
                          i21 = P2.index[1];
           p += 3;
-          if (!plane_test(i00, num0.x, den0.x)) break;
-          if (!plane_test(i01, num0.y, den0.y)) break;   // (only the LAST record of the array can hold a padding slot)
-          if (!plane_test(i10, num1.x, den1.x)) break;
-          if (!plane_test(i11, num1.y, den1.y)) break;
-          if (!plane_test(i20, num2.x, den2.x)) break;
+          if (!plane_test(i00, num0.x, den0.x, SITE(0))) break;
+          if (!plane_test(i01, num0.y, den0.y, SITE(1))) break;   // (only the LAST record of the array can hold a padding slot)
+          if (!plane_test(i10, num1.x, den1.x, SITE(2))) break;
+          if (!plane_test(i11, num1.y, den1.y, SITE(3))) break;
+          if (!plane_test(i20, num2.x, den2.x, SITE(4))) break;
           if (i21 != CTR_PLANE_PAD) {
-            if (!plane_test(i21, num2.y, den2.y)) break;
+            if (!plane_test(i21, num2.y, den2.y, SITE(5))) break;
           }
         } else {
           const CADDR DPlanePair &P0 = AK->planes[p];
+          CTR_MARK(7);  // one plane record
           float2_ num0, den0;
           num_den(P0, num0, den0);
           const uint32_t i00 = P0.index[0], i01 = P0.index[1];
           p += 1;
-          if (!plane_test(i00, num0.x, den0.x)) break;
+          if (!plane_test(i00, num0.x, den0.x, SITE(6))) break;
           if (i01 != CTR_PLANE_PAD) {
-            if (!plane_test(i01, num0.y, den0.y)) break;
+            if (!plane_test(i01, num0.y, den0.y, SITE(7))) break;
           }
         }
       }
@@ -555,6 +593,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     }
     TSTAMP(t_planes1);
     TACC(1, t_loop0, t_planes1);
+    CTR_MARK(8);  // after the planes
     // ---- spheres and stand-alone triangles, scene order ----
     // sphere::intersect normalises the direction first (default_schema.hpp:227): once per cast (at the
     // first sphere the cast meets), not once per sphere
@@ -568,12 +607,14 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       const CADDR DObj &O = AK->oloop[oi];
       const uint32_t i = O.index;
       const uint32_t type = O.type;
+      CTR_MARK(9);  // a sphere or stand-alone triangle
       bool ok = false;
       float cand = INFINITY;
       int ctri = -1;
       if (type == CTR_OBJ_SPHERE) {
         // ---- sphere::intersect, default_schema.hpp:226-251 ----
         if (!sph_have) {
+          CTR_MARK(10);
           float sx_ = rd.x, sy_ = rd.y, sz_ = rd.z;
           PIN3(sx_, sy_, sz_);  // keeps the normalisation out of scenes without spheres (no hoisting)
           sph_d = vnormalized(mk(sx_, sy_, sz_));
@@ -590,6 +631,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         // signals a miss) — so the square root and the two divisions run only if some live lane has
         // sub >= 0 or NaN (the exact reference value of sub decides, no margin involved)
         if (BALLOT(live && !(sub < 0.0f)) != 0ull) {
+          CTR_MARK(11);  // sphere roots
           const float sq = sqrtf(sub);
           const float t0 = (dec - sq) / dd, t1 = (dec + sq) / dd;
           const bool t0v = __builtin_isfinite(t0) && min_t <= t0, t1v = __builtin_isfinite(t1) && min_t <= t1;
@@ -609,6 +651,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         cand = t0;
         ctri = (int)O.tri_begin;
       }
+      CTR_MARK(12);  // object loop: candidate merge
       // ray_cast.hpp:43 — strict <, first object in scene order wins ties
       if (live && ok && cand > min_t && (cand < best || (cand == best && (int)i < bobj))) {
         best = cand;
@@ -624,6 +667,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     //      matter: the winner is the lexicographic minimum of (t, scene index). ----
     TSTAMP(t_oloop1);
     TACC(2, t_planes1, t_oloop1);
+    CTR_MARK(13);
     if (AK->n_mesh != 0u) {
       uint32_t t_pend = AK->tlas_root;           // next top-level item: inner node or mesh leaf
       uint32_t t_stack_v = 0, t_sp = 0;        // wave-uniform stack in the lanes of one VGPR
@@ -632,8 +676,12 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         if (ANYHIT) {
           if (BALLOT(live) == 0ull) break;
         }
+        // (nothing left: TL_NONE has no leaf flag, and without this test a scene's LAST mesh was followed by one more
+        //  descent set-up — ~30 vector instructions per cast for nothing, found by the execution profile, scripts/dynamic_mix.py)
+        if (t_pend == TL_NONE) break;
         // descend the top-level tree to the next mesh leaf
         if (!(t_pend & BVH_LEAF_FLAG)) {
+          CTR_MARK(14);  // top-level descent set-up
           const mask_t lv_m = BALLOT(live);
           const float t_lim = anyhit_cast ? light_dist : best;
           // conservative box test constants, as in the per-mesh walk below (world-space margin
@@ -652,6 +700,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               ((ANYHIT && ((uint32_t)__builtin_amdgcn_readlane((int)msp, t_lead) >> 31) != 0u) ? 7u : 0u);
           while (t_pend != TL_NONE && !(t_pend & BVH_LEAF_FLAG)) {
             const CADDR DNode &N = A.nodes[AK->tlas_begin + t_pend];
+            CTR_MARK(15);  // top-level node
             auto t_hits = [&](int c) -> mask_t {
               const float t1x = __builtin_fmaf(N.mn[0][c], ria.x, -t_ka.x), t2x = __builtin_fmaf(N.mx[0][c], ria.x, -t_kb.x);
               const float t1y = __builtin_fmaf(N.mn[1][c], ria.y, -t_ka.y), t2y = __builtin_fmaf(N.mx[1][c], ria.y, -t_kb.y);
@@ -683,6 +732,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             }
           }
         }
+        CTR_MARK(16);
         if (t_pend == TL_NONE) break;
         const CADDR DObj &O = AK->meshes[t_pend & 0xFFFFFFu];
         // advance first, so that `continue` below moves on to the next mesh
@@ -692,6 +742,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         } else {
           t_pend = TL_NONE;
         }
+        CTR_MARK(17);  // a mesh: AABB test
         const uint32_t i = O.index;
         bool ok = false;
         float cand = INFINITY;
@@ -722,12 +773,15 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             const mask_t border = live_m & (~(def_hit | def_miss) | FCMP(ria_big, 1e29f, FC_OGE));
             bb_m = live_m & def_hit & ~border;
             if (border != 0ull) {
+              CTR_MARK(18);  // exact AABB for borderline lanes
               if (!have_rinv) {  // wave-uniform: the exact reciprocals are computed at most once per cast
+                CTR_MARK(19);
                 float ox = rd.x, oy = rd.y, oz = rd.z;
                 PIN3(ox, oy, oz);  // keeps the three IEEE divisions in this rarely-taken branch (no hoisting)
                 rinv = mk(1.0f / ox, 1.0f / oy, 1.0f / oz);  // default_schema.hpp:103
                 have_rinv = true;
               }
+              CTR_MARK(20);
               float tmin = 0.0f, tmax = INFINITY;
               float t1 = (O.f[0] - ro.x) * rinv.x, t2 = (O.f[3] - ro.x) * rinv.x;
               tmin = smin(smax(t1, tmin), smax(t2, tmin));
@@ -743,8 +797,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           }
           TSTAMP(t_bb);
           TACC(3, t_tl0, t_bb);
+          CTR_MARK(21);
           if (bb_m == 0ull) continue;  // no lane of this wave needs the mesh
           const mask_t bb0_m = bb_m;
+          CTR_MARK(22);  // mesh entered: walk set-up
           const uint32_t beg = O.tri_begin, cnt = O.tri_count;
           if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
           if (STATS) st[4]++;
@@ -764,6 +820,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           const float2_ ro_xy = {ro.x, ro.y};
           // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
           auto tri_test = [&](const auto &T, uint32_t tri_index, mask_t lanes_m) {
+            CTR_MARK(23);  // triangle: prefilter stage 1
             mask_t c_m = lanes_m;
             if (STATS) { st[2]++; st[7] += __builtin_popcountll(lanes_m); pl_tris += INVB(lanes_m) ? 1u : 0u; }
             // d = p2 - start (default_schema.hpp:58): x and y in one packed subtraction (same IEEE result)
@@ -816,6 +873,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               c_m = lanes_m & (~rej | flat_m);
               if (c_m == 0ull) return;
               if (t_filter) {
+                CTR_MARK(24);  // prefilter stage 2
                 // Second stage, only when some lane survived the first: the ray parameter.
                 // t0 = A0/alpha with A0 = det[a b d] = d.(a x b); E0 bounds the rounding of A0 the
                 // way E does for the other three.  A lane whose t0 is certainly below min_t or
@@ -833,23 +891,27 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 #endif
 #ifndef CTR_NO_OCC
                 if (anyhit_m != 0ull) {  // wave-uniform: lane masks must never be updated under a per-lane branch
+                  CTR_MARK(25);
                   // a deciding shadow ray needs no value at all: clearly inside the triangle and
                   // clearly between min_t and the light = occluded, no exact test
                   const mask_t in_m = FCMP(sA1, E, FC_OGT) & FCMP(sA2, E, FC_OGT) & FCMP(sA1 + sA2, absa - E, FC_OLT);
                   const mask_t tin_m = FCMP(sA0 - E0, min_t * a_hi, FC_OGT) & FCMP(sA0 + E0, light_dist * a_lo, FC_OLT);
                   const mask_t occ_m = c_m & in_m & tin_m & ~flat_m & anyhit_m;
                   if (occ_m != 0ull) {
+                    CTR_MARK(26);
                     if (INVB(occ_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }  // the handler only asks best < light_dist
                     bb_m &= ~occ_m;
                     c_m &= ~occ_m;
                   }
                 }
 #endif
+                CTR_MARK(27);
                 if (c_m == 0ull) return;
               }
             }
             if (c_m == 0ull) return;
             if (STATS) { st[3]++; st[8] += __builtin_popcountll(c_m); }
+            CTR_MARK(28);  // exact test
             bool retire = false;  // any-hit: this lane found its occluder
             if (INVB(c_m)) {
               // ---- triangle::intersect, default_schema.hpp:57-78: the four determinants in the
@@ -873,6 +935,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               float t0 = tq;
               bool exact_t = false;
               if (!(def_rej | def_acc)) {
+                CTR_MARK(29);  // the reference's three divisions
                 // borderline (or NaN/inf): the reference's own arithmetic
                 const float beta = A1 / alpha, gamma = A2 / alpha;
                 t0 = A0 / alpha;
@@ -880,18 +943,23 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                 acc = beta >= 0 && gamma >= 0 && beta + gamma <= 1 && __builtin_isfinite(t0) && min_t <= t0;
               }
               if (acc) {
+                CTR_MARK(30);
                 if (anyhit_now) {
+                  CTR_MARK(121);
                   // A deciding shadow ray only asks whether some valid t lies in (min_t, light_dist).
                   // tq is within et of the exact t0 and already > min_t + et, so divide only when tq is
                   // within et of the light distance.
-                  if (!exact_t && !(tq + et < light_dist) && !(tq - et >= light_dist)) t0 = A0 / alpha;
+                  if (!exact_t && !(tq + et < light_dist) && !(tq - et >= light_dist)) { CTR_MARK(122); t0 = A0 / alpha; }
+                  CTR_MARK(123);
                   if (t0 > min_t && t0 < light_dist) {
                     best = t0; bobj = (int)i;   // any value < light_dist: the handler only compares
                     retire = true;
                   }
                 } else {
+                  CTR_MARK(124);
                   // the exact value of t0 matters only if it can beat or tie the nearest hit so far
-                  if (!exact_t && !(tq - et > lim)) { t0 = A0 / alpha; exact_t = true; }
+                  if (!exact_t && !(tq - et > lim)) { CTR_MARK(125); t0 = A0 / alpha; exact_t = true; }
+                  CTR_MARK(126);
                   const uint32_t orig = T.orig;
                   if (exact_t && (t0 < mt || (t0 == mt && orig < morig))) {
                     mt = t0; mk_ = (int)tri_index; morig = orig;
@@ -900,6 +968,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                 }
               }
             }
+            CTR_MARK(31);
             if (ANYHIT) {
               const mask_t rm = BALLOT(retire);
               bb_m &= ~rm;
@@ -967,6 +1036,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             };
             auto leaf = [&](uint32_t desc, mask_t lanes) {
               TSTAMP(t_leaf0);
+              CTR_MARK(80);  // a leaf's triangles
               const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
               for (uint32_t k = 0; k < n_l; ++k) {
                 tri_test(A.tris[first + k], first + k, lanes & bb_m);
@@ -995,6 +1065,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 #endif
             for (;;) {
               if (STATS) st[1]++;
+              CTR_MARK(32);  // BVH node
               const CADDR DNode4 &N = nodes4[cur];
               mask_t h0, h1, h2, h3;
               box_hits2(N, 0, h0, h1);
@@ -1009,27 +1080,34 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               // ONE pass, farthest child first: a hit leaf is tested at once; a hit inner child becomes the node to
               // visit next and whatever was to be visited next is pushed — so the nearest inner child is visited
               // next and the stack pops nearest-first.  No per-child bookkeeping beyond two scalar tests.
+              CTR_MARK(33);  // child dispatch
               uint32_t next = 0xFFFFFFFFu;
               bool done = false;
-#define CTR_CHILD(e, g)                                             \
+#define CTR_CHILD(e, g, id)                                         \
+  CTR_MARK(id);                                                     \
   if (!done && (g) != 0ull) {                                       \
+    CTR_MARK(id + 5);                                               \
     if ((e) & BVH_LEAF_FLAG) {                                      \
       leaf((e), (g));                                               \
+      CTR_MARK(id + 10);                                            \
       if (ANYHIT) {                                                 \
         if (bb_m == 0ull) done = true;                              \
       }                                                             \
     } else {                                                        \
+      CTR_MARK(id + 15);                                            \
       if (next != 0xFFFFFFFFu) push(next);                          \
       next = (e);                                                   \
     }                                                               \
   }
-              CTR_CHILD(e3, g3)
-              CTR_CHILD(e2, g2)
-              CTR_CHILD(e1, g1)
-              CTR_CHILD(e0, g0)
+              CTR_CHILD(e3, g3, 60)
+              CTR_CHILD(e2, g2, 61)
+              CTR_CHILD(e1, g1, 62)
+              CTR_CHILD(e0, g0, 63)
 #undef CTR_CHILD
+              CTR_MARK(34);
               if (done) break;
               if (next == 0xFFFFFFFFu) {
+                CTR_MARK(81);
                 if (sp == 0) break;
                 sp--;
                 next = __builtin_amdgcn_readlane(stack_v, sp);
@@ -1053,6 +1131,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             st[9] += (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_nodes);
             st[10] += (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_tris);
           }
+          CTR_MARK(35);  // mesh left
           if (ANYHIT) live = live && !INVB(bb0_m & ~bb_m);  // lanes retired inside the mesh
           ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
           cand = mt;
@@ -1080,6 +1159,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     }
     const bool was_hit = bobj >= 0;
     TSTAMP(t_loop1);
+    CTR_MARK(36);  // continuation
 
     // =====================================================================
     // continuation: what did this lane cast the ray for?
@@ -1091,13 +1171,16 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       V3 normal = mk(0, 0, 0);
       if (was_hit) {
         const CADDR DObj &H = AK->objs[bobj];
+        CTR_MARK(37);  // hit record
         mat_i = H.mat;
         pos = vadd(ro, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
         float unused_n0;
         const V3 hit_dn = vnormalized_n(in_d, unused_n0);
+        CTR_MARK(92);
         set_in_dn(hit_dn);
         const uint32_t ht = H.type;
         if (ht == CTR_OBJ_SPHERE) {
+          CTR_MARK(38);
           // default_schema.hpp:245-246: hit uses the NORMALIZED direction
           const V3 hit = vadd(ro, vscale(hit_dn, best));
           normal = vnormalized(vsub(hit, mk(H.f[0], H.f[1], H.f[2])));
@@ -1110,27 +1193,32 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           normal = mk(AK->gnorm[4 * btri + 0], AK->gnorm[4 * btri + 1], AK->gnorm[4 * btri + 2]);
         }
       }
+      CTR_MARK(39);
       if (first_trip) {
         // kernel.hpp:55-56 (depth = +inf, normal = 0 on a miss)
+        CTR_MARK(40);
         const size_t px_id = px_index();
         if (HOSTOUT) __hip_atomic_store(depth_out + px_id, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else depth_out[px_id] = best;
         store3(normal_out, px_id, normal);
         first_depth = best;
       }
+      CTR_MARK(41);
       if (!was_hit) {
         out_rgb = mk(0.f, 0.f, 0.f);  // shading.hpp:119
         act = ACT_UNWIND;
       } else {
         // phong prologue, shading.hpp:66-76
+        CTR_MARK(42);
         const CADDR DMat &M = AK->mats[mat_i];
         fin = vscale(mk(M.cx, M.cy, M.cz), ambient);
-        { float unused_n; set_nn(vnormalized_n(normal, unused_n)); }
+        { float unused_n; const V3 nrm_ = vnormalized_n(normal, unused_n); CTR_MARK(93); set_nn(nrm_); }
         li = 0;
         act = ACT_LIGHT;
       }
     } else if (MSP_IS_SHADOW(msp)) {
       // ---- one iteration of shadow_intensity's loop, shading.hpp:32-42 ----
+      CTR_MARK(43);
       bool done_shadow;
       float shadow_fac = 0.f;
       if (was_hit && best < light_dist) {
@@ -1149,6 +1237,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       if (done_shadow) {
         if (shadow_fac < 1.0f) {
           // shading.hpp:86-95
+          CTR_MARK(44);  // shade one light
           const CADDR DMat &M = AK->mats[mat_i];
           const CADDR DLight &Lg = AK->lights[li];
           const V3 diffuse = mk(M.cx, M.cy, M.cz);
@@ -1174,6 +1263,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           const V3 ls = vmul(specular, color);
           fin = vadd(fin, vscale(vadd(vscale(ld, fd), vscale(ls, fs)), 1 - shadow_fac));
         }
+        CTR_MARK(45);
         li++;
         act = ACT_LIGHT;
       }
@@ -1181,9 +1271,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 
     TSTAMP(t_cont_mid);
     TACC(7, t_loop1, t_cont_mid);
+    CTR_MARK(46);
     if (act == ACT_LIGHT) {
       if (li < AK->n_light) {
         // shading.hpp:79-85: direction/distance to light li, shadow ray from *hit
+        CTR_MARK(47);  // next light
         const CADDR DLight &Lg = AK->lights[li];
         V3 direction;
         float distance;
@@ -1191,11 +1283,15 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           direction = vscale(mk(Lg.vx, Lg.vy, Lg.vz), -1.0f);
           distance = INFINITY;
         } else {                         // default_schema.hpp:305-308
+          CTR_MARK(48);  // point light
           const V3 diff = vsub(mk(Lg.vx, Lg.vy, Lg.vz), ro);  // ro == *hit
           direction = vnormalized_n(diff, distance);
+          CTR_MARK(94);
         }
+        CTR_MARK(49);
         float dir_norm;
         rd = vnormalized_n(direction, dir_norm);  // shadow ray {*hit, direction.normalized()}, shading.hpp:80
+        CTR_MARK(95);
         light_dist = distance * dir_norm;
         intensity = 0.0f;
         min_t = (float)(0.0 + 1e-3);  // last_hit = 0
@@ -1207,6 +1303,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 
     if (act == ACT_BOUNCE) {
       // shading.hpp:126-150 with rgb = fin
+      CTR_MARK(50);
       const CADDR DMat &M = AK->mats[mat_i];
       const float reflective = M.reflexivity, translucent = M.transparency;
       const int sp = MSP_DEPTH(msp);
@@ -1214,12 +1311,15 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       const bool do_refl = more && (double)reflective >= 1e-6;
       const bool do_trans = more && (double)translucent >= 1e-6;
       if (do_refl || do_trans) {
+        CTR_MARK(51);  // push a frame, cast the child
         STK(sp, F_R) = fin.x; STK(sp, F_G) = fin.y; STK(sp, F_B) = fin.z;
         STK(sp, F_MAT) = __uint_as_float(mat_i | (do_refl ? 1u << 30 : 2u << 30));  // the material says reflective / translucent
         if (do_refl && do_trans) {  // the pass-through child is cast after the reflection returns
+          CTR_MARK(96);
           STK(sp, F_PX) = pos.x; STK(sp, F_PY) = pos.y; STK(sp, F_PZ) = pos.z;
           STK(sp, F_DX) = in_d.x; STK(sp, F_DY) = in_d.y; STK(sp, F_DZ) = in_d.z;
         }
+        CTR_MARK(120);
         msp = (uint32_t)(sp + 1);  // one frame deeper, a radiance cast
         if (do_refl) {
           // reflect(nd, nn) = nd - (2*(nn.nd))*nn, vector.hpp:204-206
@@ -1238,20 +1338,24 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       // return `out_rgb` to the suspended callers
       int sp = MSP_DEPTH(msp);
       for (;;) {
+        CTR_MARK(52);  // unwind one level
         if (sp == 0) {
           const size_t px_id = px_index();
           store3(color_out, px_id, out_rgb);
           msp = MSP_DONE;
           break;
         }
+        CTR_MARK(53);
         --sp;
         V3 rgb = mk(STK(sp, F_R), STK(sp, F_G), STK(sp, F_B));
         const uint32_t f_mat = __float_as_uint(STK(sp, F_MAT));
         const CADDR DMat &FM = AK->mats[f_mat & 0x3FFFFFFFu];
         const float f_transl = FM.transparency;
         if ((f_mat >> 30) == 1u) {
+          CTR_MARK(97);
           rgb = vadd(rgb, vscale(out_rgb, FM.reflexivity));  // shading.hpp:138
           if ((double)f_transl >= 1e-6) {
+            CTR_MARK(98);
             STK(sp, F_R) = rgb.x; STK(sp, F_G) = rgb.y; STK(sp, F_B) = rgb.z;
             STK(sp, F_MAT) = __uint_as_float((f_mat & 0x3FFFFFFFu) | (2u << 30));
             in_d = mk(STK(sp, F_DX), STK(sp, F_DY), STK(sp, F_DZ));
@@ -1263,6 +1367,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           }
           out_rgb = rgb;
         } else {
+          CTR_MARK(99);
           // shading.hpp:148
           out_rgb = vadd(vscale(rgb, 1.0f - f_transl), vscale(out_rgb, f_transl));
         }
@@ -1270,6 +1375,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     }
     if (first_trip) {
       // max finite depth of the tile, reduced once here instead of carrying the depth to the end
+      CTR_MARK(54);
       uint32_t dbits = (__builtin_isfinite(first_depth) && first_depth > 0.f) ? __float_as_uint(first_depth) : 0u;
       for (int off = 32; off > 0; off >>= 1) {
         const uint32_t o = (uint32_t)__shfl_xor((int)dbits, off);
@@ -1280,10 +1386,12 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     }
     TSTAMP(t_cont1);
     TACC(8, t_cont_mid, t_cont1);
+    CTR_MARK(55);
   }
 #undef STK
 #undef PRK
 
+  CTR_MARK(56);  // wave epilogue
   // (the tile's cost for the next launch's order ends here: what the group copy below costs the one wave that makes
   //  it depends on the link, not on the tile)
   const unsigned long long t_wave1 = HOSTOUT ? __builtin_readcyclecounter() : 0ull;
@@ -1304,6 +1412,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     if (lane == 0) old = atomicAdd(done, 1u);
     old = __builtin_amdgcn_readfirstlane(old);
     if (old == nt - 1) {
+      CTR_MARK(57);  // host delivery: copy a group
       if (lane == 0) *done = 0u;  // every tile of the group has counted: ready for the next launch
       const uint32_t row0 = e_ty * TH, n_rows = AE->rows.n_rows;
       const uint32_t rows_valid = n_rows - row0 < (uint32_t)TH ? n_rows - row0 : (uint32_t)TH;
@@ -1356,6 +1465,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     }
   }
 
+  CTR_MARK(58);
   if (A.cost && lane == 0) {
     const unsigned long long dt = ((HOSTOUT ? t_wave1 : __builtin_readcyclecounter()) - t_wave0) >> 6;
     const uint32_t c = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
@@ -1399,7 +1509,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     }
   }
 }
-
+#undef CTR_MARK
 // ---- after_render: block 0 folds the counter shards, block 1 builds the next dispatch order ----
 // block of CTR_SHARDS threads: thread t owns shard t; wave-level reduction, then one LDS atomic per
 // wave and word; adds into out[0..14] (max for word 1) and zeroes the shards for the next launch
@@ -1743,6 +1853,21 @@ __global__ __launch_bounds__(256) void selftest_exact_math(unsigned long long *b
   if ((threadIdx.x & 63) == 0 && wrong) atomicAdd(bad, wrong);
 }
 }  // namespace
+
+#if defined(CTR_PROFILE)
+// profile builds only (scripts/dynamic_mix.py): the segment counters, optionally cleared
+extern "C" int ctr_debug_profile_read(uint64_t *out128, int reset) {
+  unsigned int h[128];
+  if (hipDeviceSynchronize() != hipSuccess) return CTR_E_INVALID;
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)) != hipSuccess) return CTR_E_INVALID;
+  for (int q = 0; q < 128; q++) out128[q] = h[q];
+  if (reset) {
+    for (int q = 0; q < 128; q++) h[q] = 0u;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), h, sizeof(h)) != hipSuccess) return CTR_E_INVALID;
+  }
+  return CTR_OK;
+}
+#endif
 
 extern "C" int ctr_selftest_exact_math(uint64_t *n_mismatch) {
   if (!n_mismatch) return CTR_E_INVALID;

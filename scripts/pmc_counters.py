@@ -37,6 +37,7 @@ def mean(rows, key):
 
 
 sq1, grbm, fetch, write = load("sq1"), load("grbm"), load("fetch"), load("write")
+sq2, sqc = load("sq2"), load("sqc")
 cyc = mean(grbm, "GRBM_GUI_ACTIVE") / 8.0
 t_ns = mean(grbm, "t")
 fk, wk = mean(fetch, "FETCH_SIZE"), mean(write, "WRITE_SIZE")
@@ -46,6 +47,11 @@ res = {
     "valu_insts_per_launch": mean(sq1, "SQ_INSTS_VALU"), "salu_insts_per_launch": mean(sq1, "SQ_INSTS_SALU"),
     "smem_insts_per_launch": mean(sq1, "SQ_INSTS_SMEM"), "waves_per_launch": mean(sq1, "SQ_WAVES"),
     "wave_quadcycles_per_launch": mean(sq1, "SQ_WAVE_CYCLES"), "wait_any_quadcycles": mean(sq1, "SQ_WAIT_ANY"),
+    "wait_inst_any_quadcycles": mean(sq1, "SQ_WAIT_INST_ANY"),
+    "active_inst_valu_quadcycles": mean(sq2, "SQ_ACTIVE_INST_VALU"), "active_inst_any_quadcycles": mean(sq2, "SQ_ACTIVE_INST_ANY"),
+    "thread_cycles_valu": mean(sq2, "SQ_THREAD_CYCLES_VALU"),
+    "sqc_dcache_req": mean(sqc, "SQC_DCACHE_REQ"), "sqc_dcache_hits": mean(sqc, "SQC_DCACHE_HITS"),
+    "sqc_dcache_misses": mean(sqc, "SQC_DCACHE_MISSES"), "sqc_dcache_misses_duplicate": mean(sqc, "SQC_DCACHE_MISSES_DUPLICATE"),
     "cycles_per_launch": cyc, "kernel_ns_in_pmc_pass": t_ns, "effective_clock_ghz": cyc / t_ns,
     "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk, "fetch_correction": 2.0,
     "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
