@@ -274,7 +274,8 @@ class MultiScene:
         return _lib.hip_lib().ctr_multi_transport(self._h).decode()
 
     def set_variant(self, bits):
-        _lib.hip_lib().ctr_multi_set_variant(self._h, bits)
+        if _lib.hip_lib().ctr_multi_set_variant(self._h, bits):
+            raise RuntimeError(f"ctr_multi_set_variant failed: {_lib.hip_lib().ctr_last_error().decode()}")
 
     def set_size(self, w, h):
         if _lib.hip_lib().ctr_multi_set_size(self._h, w, h):
@@ -312,6 +313,43 @@ class MultiScene:
         return dict(depth=depth, color=color, normal=normal, ray_count=int(stats.ray_count), kernel_ms=stats.kernel_ms,
                     total_ms=stats.total_ms, max_depth=float(stats.max_depth), rows=int(stats.rows),
                     kernel_ms_per_device=list(ms))
+
+    def alloc_frame(self):
+        """A page-locked frame block of the group's size (ctr_frame_alloc): dict of depth / color / normal views + a
+        handle to pass to free_frame.  Page-locked destinations keep ctr_multi_submit asynchronous."""
+        L = _lib.hip_lib()
+        px = self.w * self.h
+        d, c, n = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        if L.ctr_frame_alloc(px, C.byref(d), C.byref(c), C.byref(n)):
+            raise RuntimeError("ctr_frame_alloc failed")
+        blk = np.ctypeslib.as_array(d, shape=(7 * px,))
+        return dict(depth=blk[:px].reshape(self.h, self.w), color=blk[px:4 * px].reshape(self.h, self.w, 3),
+                    normal=blk[4 * px:7 * px].reshape(self.h, self.w, 3), _ptr=d)
+
+    @staticmethod
+    def free_frame(fr):
+        _lib.hip_lib().ctr_frame_free(fr["_ptr"])
+
+    def submit(self, into, fudge=1e-3, bounces=5, block_rows=8):
+        """Queue one frame into the buffers of `into` (dict with depth / color / normal arrays of the group's size) and
+        return at once (ctr_multi_submit); at most two frames in flight."""
+        L = _lib.hip_lib()
+        st = L.ctr_multi_submit(self._h, C.c_float(fudge), bounces, block_rows, into["depth"].ctypes.data,
+                                into["color"].ctypes.data, into["normal"].ctypes.data)
+        if st:
+            raise RuntimeError(f"ctr_multi_submit failed ({st}): {L.ctr_last_error().decode()}")
+
+    def wait(self):
+        """Block until the oldest queued frame is complete (ctr_multi_wait); returns its statistics."""
+        L = _lib.hip_lib()
+        stats = RenderStats()
+        st = L.ctr_multi_wait(self._h, C.byref(stats))
+        if st:
+            raise RuntimeError(f"ctr_multi_wait failed ({st}): {L.ctr_last_error().decode()}")
+        ms = (C.c_double * len(self.devices))()
+        L.ctr_multi_kernel_ms(self._h, ms, len(self.devices))
+        return dict(ray_count=int(stats.ray_count), kernel_ms=stats.kernel_ms, total_ms=stats.total_ms,
+                    max_depth=float(stats.max_depth), rows=int(stats.rows), kernel_ms_per_device=list(ms))
 
     def _free_pinned(self):
         if getattr(self, "_pin_px", 0):

@@ -159,7 +159,9 @@ struct ctr_scene {
   unsigned long long *d_shards = nullptr;  // CTR_SHARDS x CTR_SHARD_WORDS, zero between launches
   size_t out_px = 0;
   uint32_t *d_groups = nullptr;  // host delivery: one completion counter per group of tiles (render_kernel.hip)
+  uint32_t *h_groups = nullptr;  // page-locked landing zone of the counters (checked after every direct launch)
   size_t groups_cap = 0;
+  bool poison_next_order = false;  // test hook (ctr_debug_poison_next_order)
   // tile scheduling feedback (include/cutrace_amd.h "Tile scheduling")
   uint32_t *d_cost = nullptr, *d_order = nullptr;
   uint32_t order_age = 0;  // launches of the current shape
@@ -311,6 +313,18 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
   s->order_view = view;
   if (s->order_age < 2 || !same_view || s->order_age % CTR_ORDER_PERIOD == 0) L.order_next = s->d_order;
   s->order_age++;
+  if (s->poison_next_order) {
+    // test hook: this launch gets an order whose second half names no tile — those waves leave at once, their tiles
+    // are never rendered, and (host delivery) their groups never complete
+    s->poison_next_order = false;
+    std::vector<uint32_t> o(n);
+    for (uint64_t k = 0; k < n; k++) o[k] = k < n / 2 ? (uint32_t)k : 0xFFFFFFFFu;
+    HIP_TRY(hipMemcpy(s->d_order, o.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    L.order = s->d_order;
+    L.order_init = 0;
+    L.order_next = nullptr;
+    s->order_valid = false;  // the next launch starts over
+  }
   return CTR_OK;
 }
 
@@ -742,6 +756,7 @@ void ctr_scene_destroy(ctr_scene *s) {
                   (void *)s->d_out, (void *)s->d_groups, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
     if (p) (void)hipFree(p);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
+  if (s->h_groups) (void)hipHostFree(s->h_groups);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -771,6 +786,9 @@ int ctr_scene_set_size(ctr_scene *s, uint64_t w, uint64_t h) {
 
 int ctr_set_variant(ctr_scene *s, uint32_t bits) {
   if (!s) return fail(CTR_E_INVALID, "null scene");
+  constexpr uint32_t KNOWN = CTR_VAR_NO_PREFILTER | CTR_VAR_NO_ANYHIT | CTR_VAR_NO_CLUSTER | CTR_VAR_STATS | CTR_VAR_EXACT_POW |
+                             CTR_VAR_NO_REORDER | CTR_VAR_NO_OCC6 | CTR_VAR_NO_DIRECT | CTR_VAR_IMAGE_ORDER_FIRST;
+  if (bits & ~KNOWN) return fail(CTR_E_INVALID, "ctr_set_variant: unknown variant bits " + std::to_string(bits & ~KNOWN));
   s->user_variant = bits;
   return CTR_OK;
 }
@@ -861,10 +879,15 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
       if (s->d_groups) (void)hipFree(s->d_groups);
       s->d_groups = nullptr;
       s->groups_cap = 0;
+      if (s->h_groups) (void)hipHostFree(s->h_groups);
+      s->h_groups = nullptr;
       HIP_TRY(hipMalloc((void **)&s->d_groups, groups * sizeof(uint32_t)));
-      HIP_TRY(hipMemset(s->d_groups, 0, groups * sizeof(uint32_t)));  // (every launch leaves them zeroed)
+      HIP_TRY(hipHostMalloc((void **)&s->h_groups, groups * sizeof(uint32_t), hipHostMallocDefault));
       s->groups_cap = groups;
     }
+    // cleared at the head of EVERY direct launch (a few microseconds): whatever an earlier launch left behind — one
+    // that faulted or was cut short included — this one starts from zero
+    HIP_TRY(hipMemsetAsync(s->d_groups, 0, groups * sizeof(uint32_t), nullptr));
     L.host_depth = zd;
     L.host_color = zc;
     L.host_normal = zn;
@@ -898,7 +921,23 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
     }
   }
   HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, nullptr));
+  const size_t n_groups = direct ? (size_t)ctr_staging_groups(L) : 0;
+  if (direct) HIP_TRY(hipMemcpyAsync(s->h_groups, s->d_groups, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
+  if (direct) {
+    // every group of tiles must have counted all its tiles, or its pixels never left for the caller's buffers
+    const uint32_t tiles_x = (s->cam.w + 7) / 8, groups_x = (tiles_x + 7) / 8;
+    size_t missing = 0;
+    for (size_t g = 0; g < n_groups; g++) {
+      const uint32_t gx = (uint32_t)(g % groups_x), nt = tiles_x - gx * 8 < 8 ? tiles_x - gx * 8 : 8;
+      if (s->h_groups[g] != nt) missing++;
+    }
+    if (missing) {
+      s->order_valid = false;  // whatever order that launch ran in is not to be trusted
+      return fail(CTR_E_DELIVERY, std::to_string(missing) + " of " + std::to_string(n_groups) +
+                  " tile groups were not delivered to the caller's buffers (incomplete launch); render again");
+    }
+  }
   if (direct && getenv("CUTRACE_VERIFY_DELIVERY")) {
     // Debug aid for the kernel's own delivery (render_kernel.hip "Host delivery" relies on write-through stores and
     // scoped loads instead of fences): the tile-major staging copy of the frame is still on the device — fetch it
@@ -951,6 +990,13 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
 int ctr_render(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,
                float *normal3, ctr_render_stats *stats) {
   return render_host(s, fudge, bounces, rows, depth, color3, normal3, stats, false, nullptr);
+}
+
+int ctr_debug_poison_next_order(ctr_scene *s) {
+  if (!s) return fail(CTR_E_INVALID, "null scene");
+  std::lock_guard<std::mutex> lk(s->mtx);
+  s->poison_next_order = true;
+  return CTR_OK;
 }
 
 int ctr_last_counters(ctr_scene *s, uint64_t *out16) {

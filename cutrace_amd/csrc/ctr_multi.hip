@@ -69,15 +69,21 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+constexpr int SLOTS = 2;  // frames in flight (ctr_multi_submit): frame k+1 renders while frame k is gathered and assembled
+
 struct Part {         // one device's share of the frame
   int device = 0;
   ctr_scene *scene = nullptr;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float *buf = nullptr;                  // compact [depth px | color 3 px | normal 3 px] on `device`
-  unsigned long long *counters = nullptr;
-  float *gathered = nullptr;             // the same bytes on device 0 (parts >= 1); part 0 reads `buf`
-  uint64_t rows = 0;                     // rows of the current frame this part owns
+  hipStream_t stream = nullptr;          // render kernels of this device
+  hipStream_t cstream = nullptr;         // this device's side of the gather (ncclSend); on device 0: receive, assemble, D2H
+  hipEvent_t ev0[SLOTS] = {nullptr, nullptr}, ev1[SLOTS] = {nullptr, nullptr};  // around the render kernel (timing; ev1 = "rendered")
+  hipEvent_t ev_moved[SLOTS] = {nullptr, nullptr};  // the compact buffer of the slot has left / has been read: it may be rendered into again
+  hipEvent_t ev_moved0[SLOTS] = {nullptr, nullptr}; // the same, recorded by DEVICE 0's transfer stream (peer copies; an event belongs to the device that records it)
+  hipEvent_t ev_cnt[SLOTS] = {nullptr, nullptr};    // the slot's counters have landed on the host
+  float *buf[SLOTS] = {nullptr, nullptr};           // compact [depth px | color 3 px | normal 3 px] on `device`
+  unsigned long long *counters[SLOTS] = {nullptr, nullptr};
+  float *gathered[SLOTS] = {nullptr, nullptr};      // the same bytes on device 0 (parts >= 1; part 0 only for "rccl-self")
+  uint64_t rows = 0;                     // rows of the current frame size this part owns
   ncclComm_t comm = nullptr;
 };
 
@@ -145,20 +151,45 @@ float *device_view(float *host, size_t n) {
 
 }  // namespace
 
+struct Frame {         // one slot of the pipeline
+  bool busy = false;
+  bool sync_done = false;     // the frame went through ctr_render (one device, synchronous): nothing to wait for
+  ctr_render_stats one{};     // ... and these are its statistics
+  uint64_t w = 0, h = 0;
+  hipEvent_t ev_done = nullptr;   // device 0: the frame is assembled and on its way / in the caller's buffers
+  std::chrono::high_resolution_clock::time_point t0;
+};
+
 struct ctr_multi {
   uint32_t variant = 0;
-  double single_ms = -1.0;    // kernel ms of the last call when it went through ctr_render (one device), else < 0
+  double single_ms = -1.0;    // kernel ms of the last waited frame when it went through ctr_render (one device), else < 0
   std::vector<Part> parts;
   uint64_t w = 0, h = 0;
   uint64_t cap_px = 0;        // pixels each compact buffer can hold
-  float *frame = nullptr;     // device 0: the re-interleaved frame [depth | color | normal]
+  float *frame[SLOTS] = {nullptr, nullptr};  // device 0: the re-interleaved frame [depth | color | normal]
   uint64_t frame_px = 0;
-  unsigned long long *h_counters = nullptr;  // pinned, 16 words per part
+  unsigned long long *h_counters = nullptr;  // pinned, SLOTS x 16 words per part
   bool use_rccl = false;
   std::string transport = "single";
+  Frame frames[SLOTS];
+  int head = 0, inflight = 0;  // oldest frame in flight, number in flight
+  int last = 0;                // slot of the frame waited for last (ctr_multi_kernel_ms)
 };
 
 namespace {
+
+// after an error: nothing may still be running on buffers the caller could free or reuse
+int fail_sync(ctr_multi *m, int st) {
+  for (Part &P : m->parts) {
+    if (hipSetDevice(P.device) != hipSuccess) continue;
+    if (P.stream) (void)hipStreamSynchronize(P.stream);
+    if (P.cstream) (void)hipStreamSynchronize(P.cstream);
+  }
+  for (Frame &f : m->frames) f.busy = false;
+  m->inflight = 0;
+  (void)hipGetLastError();
+  return st;
+}
 
 int ensure_buffers(ctr_multi *m, uint64_t block_rows) {
   const uint32_t n = (uint32_t)m->parts.size();
@@ -169,26 +200,32 @@ int ensure_buffers(ctr_multi *m, uint64_t block_rows) {
   }
   if (cap == 0) cap = 1;
   if (cap > m->cap_px) {
+    if (m->inflight) return mfail(CTR_E_INVALID, "ctr_multi: the frame grew while frames are in flight (ctr_multi_wait first)");
     for (uint32_t p = 0; p < n; p++) {
       Part &P = m->parts[p];
-      MHIP(hipSetDevice(P.device));
-      if (P.buf) (void)hipFree(P.buf);
-      P.buf = nullptr;
-      MHIP(hipMalloc((void **)&P.buf, sizeof(float) * 7 * cap));
-      if (p > 0) {
+      for (int q = 0; q < SLOTS; q++) {
+        MHIP(hipSetDevice(P.device));
+        if (P.buf[q]) (void)hipFree(P.buf[q]);
+        P.buf[q] = nullptr;
+        MHIP(hipMalloc((void **)&P.buf[q], sizeof(float) * 7 * cap));
+        // (part 0 has a gathered copy only under "rccl-self"; it is sized like everybody's and regrown with them —
+        //  round 2 grew only the others', and a larger frame then overran it)
         MHIP(hipSetDevice(m->parts[0].device));
-        if (P.gathered) (void)hipFree(P.gathered);
-        P.gathered = nullptr;
-        MHIP(hipMalloc((void **)&P.gathered, sizeof(float) * 7 * cap));
+        if (P.gathered[q]) (void)hipFree(P.gathered[q]);
+        P.gathered[q] = nullptr;
+        if (p > 0 || (n == 1 && m->use_rccl)) MHIP(hipMalloc((void **)&P.gathered[q], sizeof(float) * 7 * cap));
       }
     }
     m->cap_px = cap;
   }
-  if (m->w * m->h > m->frame_px) {
+  if (m->w * m->h > m->frame_px && n > 1) {
+    if (m->inflight) return mfail(CTR_E_INVALID, "ctr_multi: the frame grew while frames are in flight (ctr_multi_wait first)");
     MHIP(hipSetDevice(m->parts[0].device));
-    if (m->frame) (void)hipFree(m->frame);
-    m->frame = nullptr;
-    MHIP(hipMalloc((void **)&m->frame, sizeof(float) * 7 * m->w * m->h));
+    for (int q = 0; q < SLOTS; q++) {
+      if (m->frame[q]) (void)hipFree(m->frame[q]);
+      m->frame[q] = nullptr;
+      MHIP(hipMalloc((void **)&m->frame[q], sizeof(float) * 7 * m->w * m->h));
+    }
     m->frame_px = m->w * m->h;
   }
   return CTR_OK;
@@ -217,13 +254,23 @@ int ctr_multi_create(const ctr_scene_desc *desc, const int *devices, int n_devic
     if (st) { ctr_multi_destroy(m); return st; }
     hipError_t e = hipSetDevice(devices[i]);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&P.ev0);
-    if (e == hipSuccess) e = hipEventCreate(&P.ev1);
-    if (e == hipSuccess) e = hipMalloc((void **)&P.counters, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&P.cstream, hipStreamNonBlocking);
+    for (int q = 0; q < SLOTS && e == hipSuccess; q++) {
+      e = hipEventCreate(&P.ev0[q]);
+      if (e == hipSuccess) e = hipEventCreate(&P.ev1[q]);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&P.ev_moved[q], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&P.ev_cnt[q], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipSetDevice(devices[0]);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&P.ev_moved0[q], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipSetDevice(devices[i]);
+      if (e == hipSuccess) e = hipMalloc((void **)&P.counters[q], 16 * sizeof(unsigned long long));
+    }
     if (e != hipSuccess) { ctr_multi_destroy(m); return mfail(CTR_E_HIP_BASE + (int)e, std::string("ctr_multi_create: ") + hipGetErrorString(e)); }
   }
-  hipError_t e = hipHostMalloc((void **)&m->h_counters, sizeof(unsigned long long) * 16 * n_devices, hipHostMallocDefault);
-  if (e != hipSuccess) { ctr_multi_destroy(m); return mfail(CTR_E_HIP_BASE + (int)e, "ctr_multi_create: hipHostMalloc"); }
+  hipError_t e = hipHostMalloc((void **)&m->h_counters, sizeof(unsigned long long) * 16 * n_devices * SLOTS, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipSetDevice(devices[0]);
+  for (int q = 0; q < SLOTS && e == hipSuccess; q++) e = hipEventCreateWithFlags(&m->frames[q].ev_done, hipEventDisableTiming);
+  if (e != hipSuccess) { ctr_multi_destroy(m); return mfail(CTR_E_HIP_BASE + (int)e, "ctr_multi_create: hipHostMalloc / events"); }
   const char *force = getenv("CUTRACE_MULTI_TRANSPORT");  // "peer" forces hipMemcpyPeerAsync; "rccl-self" see below
   if (n_devices == 1 && force && !strcmp(force, "rccl-self") && g_rccl.load()) {
     // Self-test of the RCCL plumbing on a one-GPU box: a one-rank communicator, and the frame travels through one
@@ -269,21 +316,36 @@ int ctr_multi_create(const ctr_scene_desc *desc, const int *devices, int n_devic
 
 void ctr_multi_destroy(ctr_multi *m) {
   if (!m) return;
+  for (Part &P : m->parts) {  // nothing may be running when the buffers go
+    if (hipSetDevice(P.device) != hipSuccess) continue;
+    if (P.stream) (void)hipStreamSynchronize(P.stream);
+    if (P.cstream) (void)hipStreamSynchronize(P.cstream);
+  }
   for (Part &P : m->parts) {
     (void)hipSetDevice(P.device);
     if (P.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(P.comm);
-    if (P.buf) (void)hipFree(P.buf);
-    if (P.counters) (void)hipFree(P.counters);
-    if (P.ev0) (void)hipEventDestroy(P.ev0);
-    if (P.ev1) (void)hipEventDestroy(P.ev1);
+    for (int q = 0; q < SLOTS; q++) {
+      if (P.buf[q]) (void)hipFree(P.buf[q]);
+      if (P.counters[q]) (void)hipFree(P.counters[q]);
+      if (P.ev0[q]) (void)hipEventDestroy(P.ev0[q]);
+      if (P.ev1[q]) (void)hipEventDestroy(P.ev1[q]);
+      if (P.ev_moved[q]) (void)hipEventDestroy(P.ev_moved[q]);
+      if (P.ev_moved0[q]) (void)hipEventDestroy(P.ev_moved0[q]);
+      if (P.ev_cnt[q]) (void)hipEventDestroy(P.ev_cnt[q]);
+    }
     if (P.stream) (void)hipStreamDestroy(P.stream);
+    if (P.cstream) (void)hipStreamDestroy(P.cstream);
     if (P.scene) ctr_scene_destroy(P.scene);
   }
   if (!m->parts.empty()) {
     (void)hipSetDevice(m->parts[0].device);
     for (Part &P : m->parts)
-      if (P.gathered) (void)hipFree(P.gathered);
-    if (m->frame) (void)hipFree(m->frame);
+      for (int q = 0; q < SLOTS; q++)
+        if (P.gathered[q]) (void)hipFree(P.gathered[q]);
+    for (int q = 0; q < SLOTS; q++) {
+      if (m->frame[q]) (void)hipFree(m->frame[q]);
+      if (m->frames[q].ev_done) (void)hipEventDestroy(m->frames[q].ev_done);
+    }
   }
   if (m->h_counters) (void)hipHostFree(m->h_counters);
   delete m;
@@ -301,6 +363,7 @@ int ctr_multi_size(const ctr_multi *m, uint64_t *w, uint64_t *h) {
 
 int ctr_multi_set_size(ctr_multi *m, uint64_t w, uint64_t h) {
   if (!m) return mfail(CTR_E_INVALID, "null group");
+  if (m->inflight) return mfail(CTR_E_INVALID, "ctr_multi_set_size: frames in flight (ctr_multi_wait first)");
   for (Part &P : m->parts) {
     int st = ctr_scene_set_size(P.scene, w, h);
     if (st) return st;
@@ -312,19 +375,37 @@ int ctr_multi_set_size(ctr_multi *m, uint64_t w, uint64_t h) {
 
 int ctr_multi_set_variant(ctr_multi *m, uint32_t bits) {
   if (!m) return mfail(CTR_E_INVALID, "null group");
-  for (Part &P : m->parts) ctr_set_variant(P.scene, bits);
+  for (Part &P : m->parts) {
+    int st = ctr_set_variant(P.scene, bits);
+    if (st) return st;
+  }
   m->variant = bits;
   return CTR_OK;
 }
 
-int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows, float *depth, float *color3,
-                     float *normal3, ctr_render_stats *stats) {
-  auto t0 = std::chrono::high_resolution_clock::now();
+// ---- the pipeline ----
+// ctr_multi_submit queues one frame and returns; ctr_multi_wait returns when the OLDEST queued frame is in the caller's
+// buffers.  Two frames may be in flight, each in its own slot of every buffer.  Per device a render stream and a
+// transfer stream: the kernel of frame k+1 starts as soon as that of frame k is done, while frame k's compact buffers
+// travel to device 0 (one grouped ncclSend / ncclRecv), are re-interleaved there and leave for the host.  What orders them:
+//   ev1[slot]       rendered      -> the device's send / device 0's assembly may read the compact buffer
+//   ev_moved[slot]  sent / read   -> the render stream may write the compact buffer again (frame k+2)
+//   ev_done[slot]   assembled, copied out -> ctr_multi_wait
+// ctr_render_multi = submit + wait.  One device with a page-locked or pageable destination goes through ctr_render
+// (host delivery / its own copies) and is synchronous; "page-locked" is what makes the final D2H asynchronous at all.
+int ctr_multi_submit(ctr_multi *m, float fudge, int bounces, uint64_t block_rows, float *depth, float *color3, float *normal3) {
   if (!m) return mfail(CTR_E_INVALID, "null group");
+  if (m->inflight >= SLOTS) return mfail(CTR_E_INVALID, "ctr_multi_submit: two frames are in flight already (ctr_multi_wait first)");
   if (block_rows == 0) block_rows = 8;
   const uint32_t n = (uint32_t)m->parts.size();
   int st = ensure_buffers(m, block_rows);
   if (st) return st;
+  const int q = (m->head + m->inflight) % SLOTS;
+  Frame &F = m->frames[q];
+  F.t0 = std::chrono::high_resolution_clock::now();
+  F.sync_done = false;
+  F.w = m->w;
+  F.h = m->h;
   const uint64_t w = m->w, h = m->h, fpx = w * h;
   Part &P0 = m->parts[0];
   // Page-locked destinations are written by device 0 itself: through ctr_render's host delivery when there is one
@@ -333,87 +414,104 @@ int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows
   float *zd = nullptr, *zc = nullptr, *zn = nullptr;
   const bool direct = fpx && !(m->variant & CTR_VAR_NO_DIRECT) && (zd = device_view(depth, fpx)) &&
                       (zc = device_view(color3, 3 * fpx)) && (zn = device_view(normal3, 3 * fpx));
-  m->single_ms = -1.0;
-  if (direct && n == 1 && !m->use_rccl) {  // one device: ctr_render's own host delivery
-    ctr_render_stats one{};
-    if ((st = ctr_render(P0.scene, fudge, bounces, nullptr, depth, color3, normal3, &one))) return st;
-    m->single_ms = one.kernel_ms;
-    if (stats) {
-      *stats = one;
-      stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
-    }
+  const bool dest_pinned = fpx && depth && color3 && normal3 && pinned(depth) && pinned(depth + fpx - 1) && pinned(color3) &&
+                           pinned(color3 + 3 * fpx - 1) && pinned(normal3) && pinned(normal3 + 3 * fpx - 1);
+  if (n == 1 && !m->use_rccl && (direct || !dest_pinned)) {
+    // one device: ctr_render is the better path both for page-locked destinations (delivered by the kernel) and for
+    // pageable ones (its three plain copies: 2.2 ms per 1080p frame where queuing them on a side stream took 4.8)
+    if ((st = ctr_render(P0.scene, fudge, bounces, nullptr, depth, color3, normal3, &F.one))) return st;
+    F.sync_done = true;
+    F.busy = true;
+    m->inflight++;
     return CTR_OK;
   }
-  // ---- 1. every device renders its interleaved row blocks into its compact buffer ----
+  unsigned long long *hc = m->h_counters + (size_t)16 * n * q;
+  // ---- 1. every device renders its interleaved row blocks into its compact buffer of this slot ----
   for (uint32_t p = 0; p < n; p++) {
     Part &P = m->parts[p];
-    MHIP(hipSetDevice(P.device));
-    MHIP(hipMemsetAsync(P.counters, 0, 16 * sizeof(unsigned long long), P.stream));
-    MHIP(hipEventRecord(P.ev0, P.stream));
+    if ((st = (int)hipSetDevice(P.device))) return fail_sync(m, mfail(CTR_E_HIP_BASE + st, "hipSetDevice"));
+    hipError_t e = hipStreamWaitEvent(P.stream, P.ev_moved[q], 0);  // (never recorded yet: no wait)
+    if (e == hipSuccess) e = hipStreamWaitEvent(P.stream, P.ev_moved0[q], 0);
+    if (e == hipSuccess) e = hipMemsetAsync(P.counters[q], 0, 16 * sizeof(unsigned long long), P.stream);
+    if (e == hipSuccess) e = hipEventRecord(P.ev0[q], P.stream);
+    if (e != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)e, std::string("ctr_multi_submit: ") + hipGetErrorString(e)));
     const uint64_t px = P.rows * w;
     if (px) {
       ctr_rows r{0, h, block_rows, p, n};
-      st = ctr_render_device(P.scene, fudge, bounces, &r, P.buf, P.buf + px, P.buf + 4 * px, P.counters, P.stream);
-      if (st) return st;
+      st = ctr_render_device(P.scene, fudge, bounces, &r, P.buf[q], P.buf[q] + px, P.buf[q] + 4 * px, P.counters[q], P.stream);
+      if (st) return fail_sync(m, st);
     }
-    MHIP(hipEventRecord(P.ev1, P.stream));
-    MHIP(hipMemcpyAsync(m->h_counters + 16 * p, P.counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, P.stream));
+    e = hipEventRecord(P.ev1[q], P.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hc + 16 * p, P.counters[q], 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, P.stream);
+    if (e == hipSuccess) e = hipEventRecord(P.ev_cnt[q], P.stream);
+    if (e != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)e, std::string("ctr_multi_submit: ") + hipGetErrorString(e)));
   }
-  // ---- 2. one gather to device 0 ----
+  // ---- 2. one gather to device 0, on the transfer streams ----
+  hipError_t he = hipSuccess;
   if (n > 1) {
     if (m->use_rccl) {
+      for (uint32_t p = 1; p < n && he == hipSuccess; p++) {  // a device sends once its own kernel is done
+        he = hipSetDevice(m->parts[p].device);
+        if (he == hipSuccess) he = hipStreamWaitEvent(m->parts[p].cstream, m->parts[p].ev1[q], 0);
+      }
+      if (he != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)he, std::string("RCCL gather: ") + hipGetErrorString(he)));
       // (no early return between GroupStart and GroupEnd: an open group would poison every later call)
       ncclResult_t r = g_rccl.GroupStart();
-      hipError_t he = hipSuccess;
       for (uint32_t p = 1; p < n && r == ncclSuccess && he == hipSuccess; p++) {
         Part &P = m->parts[p];
         const size_t cnt = (size_t)(7 * P.rows * w);
         if (!cnt) continue;
         he = hipSetDevice(P.device);
         if (he != hipSuccess) break;
-        r = g_rccl.Send(P.buf, cnt, ncclFloat, 0, P.comm, P.stream);
+        r = g_rccl.Send(P.buf[q], cnt, ncclFloat, 0, P.comm, P.cstream);
         if (r != ncclSuccess) break;
         he = hipSetDevice(P0.device);
         if (he != hipSuccess) break;
-        r = g_rccl.Recv(P.gathered, cnt, ncclFloat, (int)p, P0.comm, P0.stream);
+        r = g_rccl.Recv(P.gathered[q], cnt, ncclFloat, (int)p, P0.comm, P0.cstream);
       }
       const ncclResult_t r2 = g_rccl.GroupEnd();
       if (r == ncclSuccess) r = r2;
-      if (he != hipSuccess) return mfail(CTR_E_HIP_BASE + (int)he, std::string("RCCL gather: ") + hipGetErrorString(he));
-      if (r != ncclSuccess) return mfail(CTR_E_HIP_BASE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r));
+      if (he != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)he, std::string("RCCL gather: ") + hipGetErrorString(he)));
+      if (r != ncclSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r)));
+      for (uint32_t p = 1; p < n && he == hipSuccess; p++) {  // sent: the compact buffer may be rendered into again
+        he = hipSetDevice(m->parts[p].device);
+        if (he == hipSuccess) he = hipEventRecord(m->parts[p].ev_moved[q], m->parts[p].cstream);
+      }
     } else {
-      MHIP(hipSetDevice(P0.device));
-      for (uint32_t p = 1; p < n; p++) {
+      he = hipSetDevice(P0.device);
+      for (uint32_t p = 1; p < n && he == hipSuccess; p++) {
         Part &P = m->parts[p];
         const size_t bytes = sizeof(float) * 7 * P.rows * w;
-        if (!bytes) continue;
-        MHIP(hipStreamWaitEvent(P0.stream, P.ev1, 0));
-        if (P.device == P0.device) MHIP(hipMemcpyAsync(P.gathered, P.buf, bytes, hipMemcpyDeviceToDevice, P0.stream));
-        else MHIP(hipMemcpyPeerAsync(P.gathered, P0.device, P.buf, P.device, bytes, P0.stream));
+        he = hipStreamWaitEvent(P0.cstream, P.ev1[q], 0);
+        if (bytes && he == hipSuccess) {
+          if (P.device == P0.device) he = hipMemcpyAsync(P.gathered[q], P.buf[q], bytes, hipMemcpyDeviceToDevice, P0.cstream);
+          else he = hipMemcpyPeerAsync(P.gathered[q], P0.device, P.buf[q], P.device, bytes, P0.cstream);
+        }
+        if (he == hipSuccess) he = hipEventRecord(P.ev_moved0[q], P0.cstream);
       }
     }
+    if (he != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)he, std::string("gather: ") + hipGetErrorString(he)));
   }
+  // device 0's transfer stream also needs device 0's own part
+  he = hipSetDevice(P0.device);
+  if (he == hipSuccess) he = hipStreamWaitEvent(P0.cstream, P0.ev1[q], 0);
+  if (he != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)he, std::string("ctr_multi_submit: ") + hipGetErrorString(he)));
   const float *self_result = nullptr;
   if (n == 1 && m->use_rccl && fpx) {  // "rccl-self": the frame goes through RCCL once, rank 0 -> rank 0
-    if (!P0.gathered) {
-      MHIP(hipSetDevice(P0.device));
-      MHIP(hipMalloc((void **)&P0.gathered, sizeof(float) * 7 * m->cap_px));
-    }
     ncclResult_t r = g_rccl.GroupStart();
-    if (r == ncclSuccess) r = g_rccl.Send(P0.buf, (size_t)(7 * fpx), ncclFloat, 0, P0.comm, P0.stream);
-    if (r == ncclSuccess) r = g_rccl.Recv(P0.gathered, (size_t)(7 * fpx), ncclFloat, 0, P0.comm, P0.stream);
+    if (r == ncclSuccess) r = g_rccl.Send(P0.buf[q], (size_t)(7 * fpx), ncclFloat, 0, P0.comm, P0.cstream);
+    if (r == ncclSuccess) r = g_rccl.Recv(P0.gathered[q], (size_t)(7 * fpx), ncclFloat, 0, P0.comm, P0.cstream);
     const ncclResult_t r2 = g_rccl.GroupEnd();
     if (r == ncclSuccess) r = r2;
-    if (r != ncclSuccess) return mfail(CTR_E_HIP_BASE, std::string("RCCL self send/recv: ") + g_rccl.GetErrorString(r));
-    self_result = P0.gathered;
+    if (r != ncclSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE, std::string("RCCL self send/recv: ") + g_rccl.GetErrorString(r)));
+    self_result = P0.gathered[q];
   }
   // ---- 3. re-interleave on device 0, 4. one D2H ----
-  MHIP(hipSetDevice(P0.device));
-  const float *result = self_result ? self_result : P0.buf;  // n == 1: the compact buffer IS the frame
+  const float *result = self_result ? self_result : P0.buf[q];  // n == 1: the compact buffer IS the frame
   if (n > 1 && fpx) {
     Reint R{};
     for (uint32_t p = 0; p < n; p++) {
-      const float *src = p == 0 ? P0.buf : m->parts[p].gathered;
+      const float *src = p == 0 ? P0.buf[q] : m->parts[p].gathered[q];
       const size_t px = (size_t)(m->parts[p].rows * w);
       R.depth[p] = src;
       R.color[p] = src + px;
@@ -423,44 +521,90 @@ int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows
     R.block_rows = (uint32_t)block_rows;
     R.w = (uint32_t)w;
     R.h = (uint32_t)h;
-    if (direct) hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, P0.stream, R, zd, zc, zn);
-    else hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, P0.stream, R, m->frame, m->frame + fpx, m->frame + 4 * fpx);
-    MHIP(hipGetLastError());
-    result = m->frame;
+    float *fr = m->frame[q];
+    if (direct) hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, P0.cstream, R, zd, zc, zn);
+    else hipLaunchKernelGGL(reinterleave_rows, dim3((uint32_t)h), dim3(256), 0, P0.cstream, R, fr, fr + fpx, fr + 4 * fpx);
+    he = hipGetLastError();
+    if (he != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)he, std::string("reinterleave_rows: ") + hipGetErrorString(he)));
+    result = fr;
   }
   if (fpx && !(direct && n > 1)) {
     const bool packed = depth && color3 == depth + fpx && normal3 == color3 + 3 * fpx;
-    if (packed && pinned(depth) && pinned(normal3 + 3 * fpx - 1)) {
-      MHIP(hipMemcpyAsync(depth, result, sizeof(float) * 7 * fpx, hipMemcpyDeviceToHost, P0.stream));
+    if (packed && dest_pinned) {
+      he = hipMemcpyAsync(depth, result, sizeof(float) * 7 * fpx, hipMemcpyDeviceToHost, P0.cstream);
     } else {
       // (hipMemcpyAsync into pageable memory is staged by the runtime and returns when the copy is done)
-      if (depth) MHIP(hipMemcpyAsync(depth, result, sizeof(float) * fpx, hipMemcpyDeviceToHost, P0.stream));
-      if (color3) MHIP(hipMemcpyAsync(color3, result + fpx, sizeof(float) * 3 * fpx, hipMemcpyDeviceToHost, P0.stream));
-      if (normal3) MHIP(hipMemcpyAsync(normal3, result + 4 * fpx, sizeof(float) * 3 * fpx, hipMemcpyDeviceToHost, P0.stream));
+      if (depth) he = hipMemcpyAsync(depth, result, sizeof(float) * fpx, hipMemcpyDeviceToHost, P0.cstream);
+      if (color3 && he == hipSuccess) he = hipMemcpyAsync(color3, result + fpx, sizeof(float) * 3 * fpx, hipMemcpyDeviceToHost, P0.cstream);
+      if (normal3 && he == hipSuccess) he = hipMemcpyAsync(normal3, result + 4 * fpx, sizeof(float) * 3 * fpx, hipMemcpyDeviceToHost, P0.cstream);
     }
+    if (he != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)he, std::string("frame copy-out: ") + hipGetErrorString(he)));
   }
-  for (uint32_t p = 0; p < n; p++) {
-    MHIP(hipSetDevice(m->parts[p].device));
-    MHIP(hipStreamSynchronize(m->parts[p].stream));
-  }
-  auto t1 = std::chrono::high_resolution_clock::now();
-  if (stats) {
-    memset(stats, 0, sizeof(*stats));
-    uint32_t bits = 0;
-    for (uint32_t p = 0; p < n; p++) {
-      float ms = 0.f;
-      MHIP(hipSetDevice(m->parts[p].device));
-      MHIP(hipEventElapsedTime(&ms, m->parts[p].ev0, m->parts[p].ev1));
-      stats->kernel_ms = stats->kernel_ms > ms ? stats->kernel_ms : ms;  // the slowest device's kernel
-      stats->ray_count += m->h_counters[16 * p + 0];
-      const uint32_t b = (uint32_t)m->h_counters[16 * p + 1];
-      bits = b > bits ? b : bits;
-    }
-    memcpy(&stats->max_depth, &bits, 4);
-    stats->rows = h;
-    stats->total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-  }
+  // device 0's compact buffer has been read once the assembly (or, n == 1, the copy-out) is through
+  he = hipEventRecord(P0.ev_moved[q], P0.cstream);
+  if (he == hipSuccess) he = hipEventRecord(F.ev_done, P0.cstream);
+  if (he != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)he, std::string("ctr_multi_submit: ") + hipGetErrorString(he)));
+  F.busy = true;
+  m->inflight++;
   return CTR_OK;
+}
+
+int ctr_multi_wait(ctr_multi *m, ctr_render_stats *stats) {
+  if (!m) return mfail(CTR_E_INVALID, "null group");
+  if (m->inflight == 0) return mfail(CTR_E_INVALID, "ctr_multi_wait: no frame in flight");
+  const int q = m->head;
+  Frame &F = m->frames[q];
+  const uint32_t n = (uint32_t)m->parts.size();
+  m->single_ms = -1.0;
+  if (F.sync_done) {
+    m->single_ms = F.one.kernel_ms;
+    if (stats) {
+      *stats = F.one;
+      stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - F.t0).count();
+    }
+  } else {
+    hipError_t e = hipSetDevice(m->parts[0].device);
+    if (e == hipSuccess) e = hipEventSynchronize(F.ev_done);
+    for (uint32_t p = 0; p < n && e == hipSuccess; p++) {
+      e = hipSetDevice(m->parts[p].device);
+      if (e == hipSuccess) e = hipEventSynchronize(m->parts[p].ev_cnt[q]);
+      if (e == hipSuccess) e = hipEventSynchronize(m->parts[p].ev_moved[q]);
+      if (e == hipSuccess) e = hipEventSynchronize(m->parts[p].ev_moved0[q]);
+    }
+    if (e != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)e, std::string("ctr_multi_wait: ") + hipGetErrorString(e)));
+    auto t1 = std::chrono::high_resolution_clock::now();
+    if (stats) {
+      memset(stats, 0, sizeof(*stats));
+      const unsigned long long *hc = m->h_counters + (size_t)16 * n * q;
+      uint32_t bits = 0;
+      for (uint32_t p = 0; p < n; p++) {
+        float ms = 0.f;
+        MHIP(hipSetDevice(m->parts[p].device));
+        MHIP(hipEventElapsedTime(&ms, m->parts[p].ev0[q], m->parts[p].ev1[q]));
+        stats->kernel_ms = stats->kernel_ms > ms ? stats->kernel_ms : ms;  // the slowest device's kernel
+        stats->ray_count += hc[16 * p + 0];
+        const uint32_t b = (uint32_t)hc[16 * p + 1];
+        bits = b > bits ? b : bits;
+      }
+      memcpy(&stats->max_depth, &bits, 4);
+      stats->rows = F.h;
+      stats->total_ms = std::chrono::duration<double, std::milli>(t1 - F.t0).count();
+    }
+  }
+  F.busy = false;
+  m->last = q;
+  m->head = (m->head + 1) % SLOTS;
+  m->inflight--;
+  return CTR_OK;
+}
+
+int ctr_render_multi(ctr_multi *m, float fudge, int bounces, uint64_t block_rows, float *depth, float *color3,
+                     float *normal3, ctr_render_stats *stats) {
+  if (!m) return mfail(CTR_E_INVALID, "null group");
+  if (m->inflight) return mfail(CTR_E_INVALID, "ctr_render_multi: frames are in flight (ctr_multi_wait first)");
+  int st = ctr_multi_submit(m, fudge, bounces, block_rows, depth, color3, normal3);
+  if (st) return st;
+  return ctr_multi_wait(m, stats);
 }
 
 int ctr_reinterleave_device(const ctr_reint_part *parts, uint32_t n_parts, uint64_t block_rows, uint64_t w, uint64_t h,
@@ -494,7 +638,7 @@ int ctr_multi_kernel_ms(ctr_multi *m, double *ms_per_device, int capacity) {
   for (int p = 0; p < (int)m->parts.size() && p < capacity; p++) {
     float ms = 0.f;
     MHIP(hipSetDevice(m->parts[p].device));
-    MHIP(hipEventElapsedTime(&ms, m->parts[p].ev0, m->parts[p].ev1));
+    MHIP(hipEventElapsedTime(&ms, m->parts[p].ev0[m->last], m->parts[p].ev1[m->last]));
     ms_per_device[p] = ms;
   }
   return CTR_OK;

@@ -1413,7 +1413,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     old = __builtin_amdgcn_readfirstlane(old);
     if (old == nt - 1) {
       CTR_MARK(57);  // host delivery: copy a group
-      if (lane == 0) *done = 0u;  // every tile of the group has counted: ready for the next launch
+      // (the counter keeps its final value nt: ctr_api.cpp clears the counters before every launch and, after it, checks
+      //  that every group counted all its tiles — a launch cut short cannot leave a later one a poisoned counter, and a
+      //  group that was never delivered is an error, not stale pixels)
       const uint32_t row0 = e_ty * TH, n_rows = AE->rows.n_rows;
       const uint32_t rows_valid = n_rows - row0 < (uint32_t)TH ? n_rows - row0 : (uint32_t)TH;
       const uint32_t x0 = t0 * TW;

@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 1
+#define CTR_ABI_VERSION 2   /* 2 (round 3): CTR_E_DELIVERY, ctr_multi_submit / ctr_multi_wait, ctr_set_variant rejects unknown bits
+                             * (1 silently ignored the bits CTR_VAR_TRI_LDS = 1, CTR_VAR_VMEM = 64, CTR_VAR_SMEM = 128 that round 2 removed) */
 
 /* ---- status codes ------------------------------------------------------- */
 #define CTR_OK 0
@@ -46,6 +47,7 @@ extern "C" {
 #define CTR_E_NO_DEVICE 2    /* no usable HIP device                          */
 #define CTR_E_IO 3           /* file could not be read / written              */
 #define CTR_E_PARSE 4        /* scene JSON rejected (loader semantics)        */
+#define CTR_E_DELIVERY 5     /* a launch that delivers the frame itself ended with tile groups undelivered */
 #define CTR_E_HIP_BASE 1000  /* 1000 + hipError_t                             */
 
 /* ---- POD vocabulary (mirrors cutrace::vector, inc/vector.hpp:25-28) ----- */
@@ -235,7 +237,20 @@ int ctr_render_multi(ctr_multi *group, float fudge, int bounces, uint64_t block_
 typedef struct ctr_reint_part { const void *d_depth, *d_color3, *d_normal3; } ctr_reint_part;
 int ctr_reinterleave_device(const ctr_reint_part *parts, uint32_t n_parts, uint64_t block_rows, uint64_t w, uint64_t h,
                             void *d_depth, void *d_color3, void *d_normal3, void *hip_stream);
-/* kernel ms of every device in the last ctr_render_multi (load balance) */
+/* The same frame-per-call work as a two-deep pipeline (round 3): ctr_multi_submit queues one frame into the caller's
+ * buffers and returns at once; ctr_multi_wait blocks until the OLDEST queued frame is complete and reports its
+ * statistics.  At most two frames may be in flight (a third submit fails with CTR_E_INVALID until one has been waited
+ * for); each device starts the kernel of frame k+1 as soon as its kernel of frame k is done, while frame k's compact
+ * buffers are gathered on device 0, re-interleaved there and copied out — the gather (58.7 MB per device at 4096 x 4096
+ * over 8 devices) and the 470 MB re-interleave hide under the next frame's rendering instead of following it.
+ * Destinations must stay valid and untouched until the matching wait; page-locked ones (ctr_frame_alloc) make the final
+ * copy asynchronous — a pageable destination still works, but its copy blocks the submitting thread.  A group of ONE
+ * device whose destination is page-locked (delivered by the render kernel) or pageable renders inside submit
+ * (synchronously, through ctr_render).  ctr_render_multi(...) == ctr_multi_submit(...) + ctr_multi_wait(...). */
+int ctr_multi_submit(ctr_multi *group, float fudge, int bounces, uint64_t block_rows, float *depth, float *color3,
+                     float *normal3);
+int ctr_multi_wait(ctr_multi *group, ctr_render_stats *stats);
+/* kernel ms of every device in the frame waited for last (load balance) */
 int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
 
 /* Kernel variant selection (tuning / ablation; default picks the fastest
@@ -268,8 +283,14 @@ int ctr_selftest_exact_math(uint64_t *n_mismatch);
  * bits; under CTR_VAR_STATS wave-level work: [4] casts (wave trips) [5] BVH nodes visited [6] triangle
  * prefilters [7] exact triangle tests [8] mesh entries [9] lanes active per cast (sum) [10] lanes whose ray
  * meets a child box of a visited node (sum) [11] lanes inside the leaf's box per prefilter (sum) [12] lanes
- * per exact test (sum): [10]/(64*[5]) etc. say how many of a wave's 64 lanes the wave-level work served. */
+ * per exact test (sum): [10]/(64*[5]) etc. say how many of a wave's 64 lanes the wave-level work served;
+ * [13] / [14]: per mesh entry the largest number of node visits / triangle tests any ONE lane had a use for, summed —
+ * what a walk by every lane for itself would take in wave steps (the bound on a per-lane walk). */
 int ctr_last_counters(ctr_scene *scene, uint64_t *out16);
+/* Test hook: the next launch on this handle gets a dispatch order whose second half names no tile, i.e. it renders
+ * half the tiles and leaves the rest untouched.  A ctr_render that delivers the frame itself then fails with
+ * CTR_E_DELIVERY; the handle stays usable (tests/test_gpu_parity.py). */
+int ctr_debug_poison_next_order(ctr_scene *scene);
 /* Diagnostic: what each 8x8 tile of the last launch cost (shader-clock ticks / 64; tile index = frame-major,
  * then row-major over the launch's tile grid).  n_tiles receives the count; out may be NULL. */
 int ctr_tile_costs(ctr_scene *scene, uint32_t *out, uint64_t capacity, uint64_t *n_tiles);

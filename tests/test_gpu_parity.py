@@ -594,6 +594,37 @@ def test_first_launch_centre_out_order_is_a_permutation(ca, w, h, rows):
     assert costs.size == ((w + 7) // 8) * ((want["depth"].shape[0] + 7) // 8) and costs.min() > 0   # every tile ran
 
 
+def test_aborted_direct_launch_is_reported_and_the_handle_recovers(ca):
+    """Host delivery keeps one completion counter per group of tiles.  A launch that is cut short (here: a dispatch order
+    whose second half names no tile, ctr_debug_poison_next_order) must not pass for a frame — ctr_render returns
+    CTR_E_DELIVERY — and must not poison the handle: the counters are cleared at the head of every launch, so the next
+    render on the SAME handle is complete and bit-identical to the device-buffer path."""
+    from cutrace_amd import _lib
+    L = _lib.hip_lib()
+    s = load_scene(ca, "bunny", 640, 360)
+    ds = ca.DeviceScene(s)
+    want = ds.render(bounces=3)                      # pageable destination: device buffers + copies
+    for _ in range(2):
+        ds.render(bounces=3, pinned=True)
+    assert L.ctr_debug_poison_next_order(ds._h) == 0
+    with pytest.raises(RuntimeError, match="not delivered"):
+        ds.render(bounces=3, pinned=True)
+    for _ in range(3):                               # first launch after the abort, then the re-sorted order
+        got = ds.render(bounces=3, pinned=True)
+        for k in ("depth", "normal", "color"):
+            assert same_bits(got[k], want[k]), k
+        assert got["ray_count"] == want["ray_count"]
+    # the same abort on the device-buffer path renders half a frame without an error code (nothing is delivered by
+    # the kernel there), and the handle is just as usable afterwards
+    assert L.ctr_debug_poison_next_order(ds._h) == 0
+    ds.render(bounces=3)
+    got = ds.render(bounces=3)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(got[k], want[k]), k
+    with pytest.raises(RuntimeError):
+        ds.set_variant(1)                            # a variant bit round 2 removed: now rejected, not ignored
+
+
 def test_delivery_self_check(ca, monkeypatch):
     """CUTRACE_VERIFY_DELIVERY=1 makes ctr_render compare what the kernel delivered into page-locked memory with the staged
     frame it still holds on the device, pixel by pixel (a debug aid): it must pass, at full size and at a ragged one."""
