@@ -14,15 +14,22 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
             cast), the fixed numerator SURVEY.md §8(d) defines; counted by the kernel itself and
             equal to the oracle's count (64 278 888 for the default workload; tested).
   roofline= the bound that binds this kernel is VALU ISSUE (the scene, <1 MB, lives in scalar cache / L2;
-            HBM carries 0.006 of its peak):  achieved = wave-level VALU instructions per launch (PMC
-            SQ_INSTS_VALU of the same command, profiles/r02/counters.json) x the mean issue cost of the
-            kernel's instruction mix (profiles/r02/valu_mix.json: static mix of the shipped ISA priced with
-            the per-kind costs MEASURED on the box by scripts/valu_issue.hip — 2.2 cycles VGPR-only, 4.1
-            with an SGPR operand / compare / packed / min3, 8.1 transcendental) / the kernel's mean
-            duration from HIP events in this run;  peak = 1024 SIMDs x the effective shader clock of the PMC
-            pass (GRBM_GUI_ACTIVE / 8 / kernel time).  frac = achieved / peak <= 1.  The HBM view (counter
-            traffic / time / 8 TB/s) is kept as roofline.hbm_frac; SURVEY §8(d)'s "bytes the reference's
-            flat traversal streams" is a property of the workload, reported in config, not a rate.
+            HBM carries 0.007 of its peak):  achieved = wave-level VALU instructions per launch (PMC
+            SQ_INSTS_VALU of the same command, profiles/r03/counters_<workload>.json) x the mean issue cost of
+            the instructions the kernel EXECUTES (profiles/r03/valu_mix_dynamic_<workload>.json: every
+            straight-line segment of the source counted at run time by a -DCTR_PROFILE build, its instructions
+            classified in the ISA of a -DCTR_MARKS build, scripts/dynamic_mix.py; cross-checked against
+            SQ_INSTS_VALU / SALU / SMEM of the shipped build) priced with the per-kind costs MEASURED on the box
+            by scripts/valu_issue.hip — 2.2 cycles VGPR-only, 4.1 with an SGPR operand / compare / packed /
+            min3, 8.1 transcendental — / the kernel's mean duration from HIP events in this run;  peak = 1024
+            SIMDs x the effective shader clock (cycles per launch of the PMC pass / this run's kernel time).
+            frac = achieved / peak <= 1; it is withheld (stale) when the kernel sources are not the ones the
+            profiles were taken on.  The same fraction for the 64 000-triangle mesh and the C4 grid:
+            config.dense_64k_roofline / config.c4_roofline.  The HBM view (counter traffic / time / 8 TB/s) is
+            kept as roofline.hbm_frac; SURVEY §8(d)'s "bytes the reference's flat traversal streams" is a
+            property of the workload, reported in config, not a rate.
+  config.c4_strong = BASELINE config 5 measured in the same run at whatever N the driver chose: the 4x4 bunny grid
+            @4096x4096, one frame per step row-tiled over the N ranks, gathered to rank 0 (frame ms, Mrays/s).
   cpu_baseline = the CPU checker (oracle/_ref = the reference's own headers built for the host
             when present, else the plain-C port) on a bounded row sample of the same workload.
 """
@@ -45,6 +52,10 @@ def parse_args():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--scene", default="scene/bunny.json")
+    p.add_argument("--workload", choices=["bunny", "c4"], default="bunny",
+                   help="bunny: --scene (default scene/bunny.json@1920x1080, BASELINE config C2, the metric's workload); "
+                        "c4: BASELINE config 5, the 4x4 bunny grid @4096x4096 (16 meshes), generated on the fly — meant for "
+                        "--scaling strong --roots rank0 (one frame per step, row-tiled over the ranks, gathered to rank 0)")
     p.add_argument("--width", type=int, default=0)
     p.add_argument("--height", type=int, default=0)
     p.add_argument("--bounces", type=int, default=5)
@@ -109,6 +120,53 @@ def cpu_baseline(ca, host_scene, bounces, div):
     }
 
 
+def campath(ca, hs, device):
+    import ctypes as C
+    import math
+    import torch
+    from cutrace_amd import _lib
+    w, h = hs.size
+    cam0 = hs.desc.contents.cam
+    N = 90
+    cams = []
+    for k in range(N):
+        c = ca.Camera()
+        C.memmove(C.byref(c), C.byref(cam0), C.sizeof(ca.Camera))
+        a = math.radians(-22.5 + 0.35 * k)
+        eye = _lib.Vec3(1.0 - 0.015 * k * 0.5, 0.1 * math.sin(k / 15.0), 2.0)
+        ang = math.radians(67.5) - a + math.radians(-22.5)
+        look = _lib.Vec3(-math.sin(ang), 0.0, -math.cos(ang))
+        _lib.host_lib().ctr_camera_look_at(C.byref(c), eye, _lib.Vec3(0, 1, 0), look)
+        cams.append(c)
+    dev = torch.device("cuda", device)
+    depth = torch.zeros(h * w, dtype=torch.float32, device=dev)
+    color = torch.zeros(h * w * 3, dtype=torch.float32, device=dev)
+    normal = torch.zeros(h * w * 3, dtype=torch.float32, device=dev)
+    counters = torch.zeros(16, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+    res = {}
+    for var, key in ((ca.VAR_NO_REORDER, "campath_ms_image_order"), (0, "campath_ms")):
+        x = ca.DeviceScene(hs, device=device)
+        x.set_cameras(cams)
+        x.set_variant(var)
+        ms = []
+        for rep_ in range(2):
+            evs = []
+            for k in range(N):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                x.render_device_batch(depth.data_ptr(), color.data_ptr(), normal.data_ptr(), n_frames=1, frame_stride_px=h * w,
+                                      first_frame=k, d_counters=counters.data_ptr(), stream=stream.cuda_stream)
+                e1.record(stream)
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in evs]
+        res[key] = sum(ms) / N
+        x.close()
+    res["campath"] = "90-frame camera path through the bunny room, one launch per frame, kernel ms per frame (mean)"
+    return res
+
+
 def extras(ca, hs, args, ds):
     """Untimed side measurements reported in `config` (never part of `value`)."""
     import statistics
@@ -168,12 +226,98 @@ def extras(ca, hs, args, ds):
         out["dense_64k_first_launch_ms"] = first["kernel_ms"]
         out["dense_64k_rays"] = first["ray_count"]
         dd.close()
+    # (3b) the first launch of a shape (image / centre-out order: no costs known yet) against the steady state for the
+    #      other single-GPU configs too — what a one-frame-per-process `cutrace <scene.json>` pays
+    if os.path.basename(args.scene) == "bunny.json":
+        d = tempfile.mkdtemp()
+        fl = {}
+        for name, path, b in (("C1 sphere_plane.json", os.path.join(ROOT, "scene", "sphere_plane.json"), 5),
+                              ("C3 mirror.json b8", os.path.join(ROOT, "scene", "mirror.json"), 8),
+                              ("C3-deep (walls reflect 0.5) b8", scenes.make_mirror_deep(d), 8)):
+            sc = ca.HostScene.load(path)
+            x = ca.DeviceScene(sc, device=ds.device)
+            x.render(bounces=b, rows=(0, 8))
+            first = x.render(bounces=b)["kernel_ms"]
+            for _ in range(3):
+                x.render(bounces=b)
+            steady = statistics.median(x.render(bounces=b)["kernel_ms"] for _ in range(7))
+            fl[name] = {"first_launch_kernel_ms": first, "steady_kernel_ms": steady}
+            x.close()
+        out["first_launch_by_config"] = fl
+        # (3c) a MOVING camera (90 frames, eye ~1.5 cm and view ~0.35 deg per frame): every frame is ordered by the costs
+        #      of the previous, different frame — against image order (scripts/gpu_campath.py's loop)
+        out.update(campath(ca, hs, ds.device))
     # (4) SURVEY §8(d): bytes the REFERENCE's flat traversal streams for this frame (56 B x objects per ray_cast +
     #     48 B x triangles of every mesh whose AABB the ray hits + 28 B per pixel) — a workload property
     alg_bytes, alg_rays = ds.algorithmic_bytes(bounces=args.bounces)
     out["reference_equivalent_bytes_per_frame"] = alg_bytes
     out["reference_rays_per_frame"] = alg_rays
     return out
+
+
+PROFILE_WORKLOADS = {"bunny": "bunny.json@1920x1080b5", "dense64k": "bunny_dense3.json@1920x1080b5",
+                     "c4": "bunny_grid4x4.json@4096x4096b5"}
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+
+
+def kernel_source_hash():
+    """What the render kernel's ISA is made from: the PMC counters and the instruction mix under profiles/ describe ONE
+    build; a roofline fraction computed from them for another build would be a stale constant."""
+    import hashlib
+    from cutrace_amd import build
+    hh = hashlib.sha256()
+    for f in ("cutrace_amd/csrc/render_kernel.hip", "cutrace_amd/csrc/scene_device.h", "cutrace_amd/csrc/bvh.h",
+              "include/cutrace_amd.h"):
+        hh.update(open(os.path.join(ROOT, f), "rb").read())
+    hh.update(" ".join(x for x in build.HIP_FLAGS if not x.startswith("-I")).encode())
+    return hh.hexdigest()[:16]
+
+
+def roofline_from_profiles(workload, kern_avg_ms, counters_json):
+    """VALU-issue roofline of the render kernel for `workload` from the committed PMC passes (counters_<tag>.json) and the
+    execution-weighted instruction mix (valu_mix_dynamic_<tag>.json, scripts/dynamic_mix.py).  kern_avg_ms > 0: this
+    run's own mean kernel time (HIP events) turns the cycle counts into rates; 0: only the fraction, which needs none."""
+    tag = next((t for t, wl in PROFILE_WORKLOADS.items() if wl == workload), None)
+    roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G SIMD-cycles/s", "frac": None,
+            "traffic": None, "kernel": "render_kernel", "kernel_ms_avg": kern_avg_ms or None,
+            "kernel_variant_bits": "1 PREFILTER | 2 ANYHIT | 8 BVH | 32 FASTPOW | 64 built for 6 waves per SIMD"}
+    cj = counters_json or (os.path.join(PROFILE_DIR, f"counters_{tag}.json") if tag else "")
+    mj = os.path.join(PROFILE_DIR, f"valu_mix_dynamic_{tag}.json") if tag else ""
+    if not (cj and os.path.exists(cj) and mj and os.path.exists(mj)):
+        return roof
+    cnt, mix = json.load(open(cj)), json.load(open(mj))
+    roof["kernel"] = cnt.get("kernel", "render_kernel")
+    if cnt.get("workload") != workload:
+        return roof
+    have, want = cnt.get("kernel_source_sha256"), kernel_source_hash()
+    if have != want:
+        roof["stale"] = f"profiles/r03 describes kernel source {have}, this tree is {want}: no fraction is claimed"
+        return roof
+    cost = mix["mean_issue_cycles_per_valu"]
+    cycles = cnt["cycles_per_launch"]
+    traffic = cnt.get("hbm_bytes_per_launch")
+    # The kernel's CYCLE count per launch is what the counters pin (same code, same work); the clock the chip holds
+    # differs between a profiled and an un-profiled run (MI355X_MICROARCH.md, DVFS).  So
+    #   frac = VALU issue cycles the launch needs / SIMD cycles it had = valu_insts x mean issue cost / (1024 x cycles_per_launch)
+    # is recomputable from profiles/r03 alone; this run's kernel time only scales achieved and peak by the same clock.
+    frac = cnt["valu_insts_per_launch"] * cost / (1024.0 * cycles)
+    roof.update({
+        "frac": frac, "traffic": traffic, "cycles_per_launch": cycles, "kernel_ms_in_pmc_pass": cnt["kernel_ns_in_pmc_pass"] * 1e-6,
+        "clock_ghz_in_pmc_pass": cnt["effective_clock_ghz"], "valu_insts_per_launch": cnt["valu_insts_per_launch"],
+        "salu_insts_per_launch": cnt.get("salu_insts_per_launch"), "smem_insts_per_launch": cnt.get("smem_insts_per_launch"),
+        "mean_issue_cycles_per_valu": cost, "valu_mix_dynamic": mix.get("class_shares"),
+        "valu_mix_cross_check": mix.get("pmc_check"),
+        "issue_cost_cycles": {"F_vgpr_only": 2.2, "H_sgpr_operand_cmp_packed_min3": 4.1, "Q_transcendental": 8.1},
+        "simds": 1024, "hbm_bytes_per_launch": traffic, "hbm_peak_gbs": HBM_PEAK_GBS,
+        "wait_any_share_of_wave_cycles": (cnt["wait_any_quadcycles"] / cnt["wave_quadcycles_per_launch"]) if cnt.get("wave_quadcycles_per_launch") else None,
+        "source": f"profiles/r03/counters_{tag}.json (rocprofv3 --pmc passes of bench.py on this workload), "
+                  f"profiles/r03/valu_mix_dynamic_{tag}.json (execution-weighted mix, scripts/dynamic_mix.py), profiles/r02/valu_issue.txt"})
+    if kern_avg_ms and kern_avg_ms > 0:
+        clock = cycles / (kern_avg_ms * 1e-3) / 1e9
+        roof.update({"achieved": cnt["valu_insts_per_launch"] * cost / (kern_avg_ms * 1e-3) / 1e9, "peak": 1024.0 * clock,
+                     "clock_ghz_this_run": clock,
+                     "hbm_frac": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None})
+    return roof
 
 
 def main():
@@ -205,100 +349,111 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload == "c4":
+        import tempfile
+        from cutrace_amd import scenes
+        args.scene = scenes.make_bunny_grid(tempfile.mkdtemp(prefix=f"c4_r{rank}_"))
     hs = ca.HostScene.load(args.scene)
     assert hs.ok, "scene failed to load"
     if args.width and args.height:
         hs.set_size(args.width, args.height)
     w, h = hs.size
-    ds = ca.DeviceScene(hs, device=local_rank)  # raises when the HIP library is missing
-    if args.variant:
-        ds.set_variant(args.variant)
-    frames = world if args.scaling == "weak" else 1
     sim = args.of if (world == 1 and args.of > 1) else 0
-    if sim:  # one process plays rank `as_rank` of `of` ranks: same launches, no collective
-        frames = sim if args.scaling == "weak" else 1
-        tiler = FrameTiler(w, h, frames, args.as_rank, sim, dev, roots=args.roots)
-        tiler.gather = lambda slot: None
-        tiler.begin = lambda slot: None
-        tiler.finish = lambda: None
-    else:
-        tiler = FrameTiler(w, h, frames, rank, world, dev, roots=args.roots)
-    if frames > 1:
-        import ctypes
-        cam0 = hs.desc.contents.cam
-        cams = []
-        for _ in range(frames):  # synthetic camera path: the scene camera repeated
-            c = ca.Camera()
-            ctypes.memmove(ctypes.byref(c), ctypes.byref(cam0), ctypes.sizeof(ca.Camera))
-            cams.append(c)
-        ds.set_cameras(cams)
-    counters = torch.zeros(16, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream()
 
-    step_no = [0]
+    def measure(hs, scaling, roots, steps, warmup, probe):
+        """One workload through the tiler: -> (ds, tiler, frames, dt_max, rays_step, kern_avg, kern_io)."""
+        w, h = hs.size
+        ds = ca.DeviceScene(hs, device=local_rank)  # raises when the HIP library is missing
+        if args.variant:
+            ds.set_variant(args.variant)
+        frames = world if scaling == "weak" else 1
+        if sim:  # one process plays rank `as_rank` of `of` ranks: same launches, no collective
+            frames = sim if scaling == "weak" else 1
+            tiler = FrameTiler(w, h, frames, args.as_rank, sim, dev, roots=roots)
+            tiler.gather = lambda slot: None
+            tiler.begin = lambda slot: None
+            tiler.finish = lambda: None
+        else:
+            tiler = FrameTiler(w, h, frames, rank, world, dev, roots=roots)
+        if frames > 1:
+            import ctypes
+            cam0 = hs.desc.contents.cam
+            cams = []
+            for _ in range(frames):  # synthetic camera path: the scene camera repeated
+                c = ca.Camera()
+                ctypes.memmove(ctypes.byref(c), ctypes.byref(cam0), ctypes.sizeof(ca.Camera))
+                cams.append(c)
+            ds.set_cameras(cams)
+        counters = torch.zeros(16, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream()
+        step_no = [0]
 
-    def render_step(events=None):
-        slot = step_no[0] % tiler.slots
-        step_no[0] += 1
-        tiler.begin(slot)  # the gather that last used this half of the double buffer must be done
-        buf = tiler.local[slot]
-        d0, c0, n0, _ = tiler.sec
-        esz = buf.element_size()
-        if events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        # ONE launch renders this rank's rows of all `frames` frames of the step (camera path batch)
-        ds.render_device_batch(buf.data_ptr() + d0 * esz, buf.data_ptr() + c0 * esz, buf.data_ptr() + n0 * esz,
-                               n_frames=frames, frame_stride_px=tiler.cap * w, d_counters=counters.data_ptr(),
-                               stream=stream.cuda_stream, fudge=1e-3, bounces=args.bounces, rows=tiler.rows,
-                               part_stride=tiler.part_stride)
-        if events is not None:
-            e1.record(stream)
-            events.append((e0, e1))
-        tiler.gather(slot)  # asynchronous: overlaps with the next step's rendering
+        def render_step(events=None):
+            slot = step_no[0] % tiler.slots
+            step_no[0] += 1
+            tiler.begin(slot)  # the gather that last used this half of the double buffer must be done
+            buf = tiler.local[slot]
+            d0, c0, n0, _ = tiler.sec
+            esz = buf.element_size()
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            # ONE launch renders this rank's rows of all `frames` frames of the step (camera path batch)
+            ds.render_device_batch(buf.data_ptr() + d0 * esz, buf.data_ptr() + c0 * esz, buf.data_ptr() + n0 * esz,
+                                   n_frames=frames, frame_stride_px=tiler.cap * w, d_counters=counters.data_ptr(),
+                                   stream=stream.cuda_stream, fudge=1e-3, bounces=args.bounces, rows=tiler.rows,
+                                   part_stride=tiler.part_stride)
+            if events is not None:
+                e1.record(stream)
+                events.append((e0, e1))
+            tiler.gather(slot)  # asynchronous: overlaps with the next step's rendering
 
-    def barrier():
-        tiler.finish()      # every outstanding gather / re-interleave completes INSIDE the timed region
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def barrier():
+            tiler.finish()      # every outstanding gather / re-interleave completes INSIDE the timed region
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    # rays per step for this rank (counting launch, untimed)
-    counters.zero_()
-    render_step()
-    barrier()
-    rays_rank_step = int(counters[0].item())
-    for _ in range(max(0, args.warmup - 1)):
+        # rays per step for this rank (counting launch, untimed)
+        counters.zero_()
         render_step()
-    barrier()
-    events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        render_step(events)
-    barrier()
-    dt = time.perf_counter() - t0
-
-    kern_ms = [a.elapsed_time(b) for a, b in events]
-    # for the record (untimed): the same launch with tiles dispatched in image order, i.e. what the
-    # first launch of a shape costs before the scheduling feedback exists
-    kern_io = None
-    if not args.skip_probe:
-        ds.set_variant(args.variant | ca.VAR_NO_REORDER)
-        ev_io = []
-        for _ in range(3):
-            render_step(ev_io)
         barrier()
-        kern_io = min(a.elapsed_time(b) for a, b in ev_io)
-        ds.set_variant(args.variant)
-    t = torch.tensor([dt, float(rays_rank_step), sum(kern_ms) / max(1, len(kern_ms))], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, rays_step, kern_avg = float(tmax[0]), float(tsum[1]), float(tsum[2]) / world
-    else:
-        dt_max, rays_step, kern_avg = dt, float(rays_rank_step), float(t[2])
+        rays_rank_step = int(counters[0].item())
+        for _ in range(max(0, warmup - 1)):
+            render_step()
+        barrier()
+        events = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            render_step(events)
+        barrier()
+        dt = time.perf_counter() - t0
+
+        kern_ms = [a.elapsed_time(b) for a, b in events]
+        # for the record (untimed): the same launch with tiles dispatched in image order, i.e. what the
+        # first launch of a shape costs before the scheduling feedback exists
+        kern_io = None
+        if probe:
+            ds.set_variant(args.variant | ca.VAR_NO_REORDER)
+            ev_io = []
+            for _ in range(3):
+                render_step(ev_io)
+            barrier()
+            kern_io = min(a.elapsed_time(b) for a, b in ev_io)
+            ds.set_variant(args.variant)
+        t = torch.tensor([dt, float(rays_rank_step), sum(kern_ms) / max(1, len(kern_ms))], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = t.clone()
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            dt_max, rays_step, kern_avg = float(tmax[0]), float(tsum[1]), float(tsum[2]) / world
+        else:
+            dt_max, rays_step, kern_avg = dt, float(rays_rank_step), float(t[2])
+        return ds, tiler, frames, dt_max, rays_step, kern_avg, kern_io
+
+    ds, tiler, frames, dt_max, rays_step, kern_avg, kern_io = measure(hs, args.scaling, args.roots, args.steps, args.warmup,
+                                                                       not args.skip_probe)
 
     if args.check and not sim:
         import numpy as np
@@ -318,49 +473,25 @@ def main():
         if rank == 0:
             print(f"check: {frames} gathered frame(s) bitwise equal to the single-process render", file=sys.stderr, flush=True)
 
+    # BASELINE config 5 next to the metric's workload, at every N the driver runs: the 4x4 bunny grid @4096x4096, ONE frame
+    # per step row-tiled over all ranks and gathered to rank 0 (strong scaling), untimed for `value`
+    c4_leg = None
+    if not args.no_extras and args.workload != "c4" and not sim and os.path.basename(args.scene) == "bunny.json" and not (args.width or args.height):
+        import tempfile
+        from cutrace_amd import scenes
+        c4_hs = ca.HostScene.load(scenes.make_bunny_grid(tempfile.mkdtemp(prefix=f"c4_r{rank}_")))
+        _, c4_tiler, _, c4_dt, c4_rays, c4_kern, _ = measure(c4_hs, "strong", "rank0", 6, 2, False)
+        c4_leg = {"workload": "4x4 bunny grid (16 meshes x 1000 triangles) @4096x4096 bounces=%d, one frame per step row-tiled "
+                              "over %d GPU(s), gathered to rank 0" % (args.bounces, world),
+                  "n_gpus": world, "steps": 6, "frame_ms": c4_dt / 6 * 1e3, "mrays_per_s": c4_rays * 6 / c4_dt / 1e6,
+                  "rays_per_frame": c4_rays, "kernel_ms_avg_over_ranks": c4_kern}
+        del c4_tiler
     if rank == 0:
         total_rays = rays_step * args.steps
         value = total_rays / dt_max / 1e6
         workload = f"{os.path.basename(args.scene)}@{w}x{h}b{args.bounces}"
         # ---- roofline of the dominant (only) kernel, per launch: VALU issue ----
-        cj = args.counters_json or os.path.join(ROOT, "profiles", "r02", "counters.json")
-        mj = os.path.join(ROOT, "profiles", "r02", "valu_mix.json")
-        cnt = json.load(open(cj)) if os.path.exists(cj) else {}
-        mixes = json.load(open(mj)) if os.path.exists(mj) else {}
-        # the instantiation the PMC pass saw ("render_kernel<107u>" -> mangled "...render_kernelILj107E...")
-        import re
-        m_ = re.search(r"render_kernel<(\d+)u>", cnt.get("kernel", ""))
-        mix = next((v for k, v in mixes.items() if m_ and f"render_kernelILj{m_.group(1)}E" in k), {})
-        roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G SIMD-cycles/s", "frac": None,
-                "traffic": None, "kernel": cnt.get("kernel", "render_kernel"), "kernel_ms_avg": kern_avg,
-                "kernel_variant_bits": "1 PREFILTER | 2 ANYHIT | 8 BVH | 32 FASTPOW | 64 built for 6 waves per SIMD"}
-        if world == 1 and frames == 1 and cnt.get("workload") == workload and mix and kern_avg > 0:
-            cost = mix["mean_issue_cycles"]
-            # The kernel's CYCLE count per launch is what the counters pin (same code, same work); the clock the chip
-            # holds differs between a profiled and an un-profiled run (MI355X_MICROARCH.md, DVFS).  So the live clock is
-            # taken as cycles_per_launch (GRBM_GUI_ACTIVE / 8 of the PMC pass) / this run's mean kernel time, and
-            #   achieved = VALU issue cycles the launch needs / kernel time,  peak = 1024 SIMDs x that clock,
-            # i.e. frac = valu_insts x mean issue cost / (1024 x cycles_per_launch): recomputable from profiles/r02 alone.
-            cycles = cnt["cycles_per_launch"]
-            clock = cycles / (kern_avg * 1e-3) / 1e9
-            achieved = cnt["valu_insts_per_launch"] * cost / (kern_avg * 1e-3) / 1e9
-            peak = 1024.0 * clock
-            traffic = cnt.get("hbm_bytes_per_launch")
-            roof.update({
-                "achieved": achieved, "peak": peak, "frac": achieved / peak, "traffic": traffic,
-                "cycles_per_launch": cycles, "kernel_ms_in_pmc_pass": cnt["kernel_ns_in_pmc_pass"] * 1e-6,
-                "clock_ghz_in_pmc_pass": cnt["effective_clock_ghz"],
-                "valu_insts_per_launch": cnt["valu_insts_per_launch"], "salu_insts_per_launch": cnt.get("salu_insts_per_launch"),
-                "smem_insts_per_launch": cnt.get("smem_insts_per_launch"),
-                "mean_issue_cycles_per_valu": cost, "valu_mix_static": {k: mix[k] for k in ("F", "H", "Q")},
-                "issue_cost_cycles": {"F_vgpr_only": 2.2, "H_sgpr_operand_cmp_packed_min3": 4.1, "Q_transcendental": 8.1},
-                "clock_ghz_this_run": clock, "simds": 1024,
-                "frac_if_every_valu_cost_2.2": cnt["valu_insts_per_launch"] * 2.2 / (kern_avg * 1e-3) / 1e9 / peak,
-                "frac_if_every_valu_cost_4.1": cnt["valu_insts_per_launch"] * 4.1 / (kern_avg * 1e-3) / 1e9 / peak,
-                "hbm_frac": (traffic / (kern_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "hbm_peak_gbs": HBM_PEAK_GBS,
-                "source": "profiles/r02/counters.json (rocprofv3 --pmc passes of this command), profiles/r02/valu_mix.json, "
-                          "profiles/r02/valu_issue.txt"})
+        roof = roofline_from_profiles(workload, kern_avg if (world == 1 and frames == 1) else 0.0, args.counters_json)
         config = {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
                               f"{frames} frame(s)/step row-tiled over {world} GPU(s), "
                               + ("frame f gathered to rank f mod N" if tiler.rotate_roots else "gather to rank 0"),
@@ -372,6 +503,13 @@ def main():
                   "unique_mrays_per_s": (rays_step - frames * w * h) * args.steps / dt_max / 1e6}
         if world == 1 and not args.no_extras:
             config.update(extras(ca, hs, args, ds))
+        if c4_leg:
+            config["c4_strong"] = c4_leg
+        for tag, key in (("dense64k", "dense_64k_roofline"), ("c4", "c4_roofline")):
+            r_ = roofline_from_profiles(PROFILE_WORKLOADS[tag], 0.0, "")
+            if r_.get("frac") is not None:  # (constants of the committed PMC passes: that scene is not timed live here)
+                config[key] = {k: r_[k] for k in ("frac", "valu_insts_per_launch", "mean_issue_cycles_per_valu", "cycles_per_launch",
+                                                  "kernel_ms_in_pmc_pass", "hbm_bytes_per_launch", "source")}
         out = {
             "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -153,6 +153,7 @@ struct ctr_scene {
   std::vector<DObj> h_objs, h_meshes;
   std::vector<DCam> h_cams;
   std::vector<DLight> h_lights;
+  std::vector<DMat> h_mats;
   unsigned long long *h_counters = nullptr;  // pinned landing zone of the 16 counter words
   unsigned long long last_cnt[16] = {0};     // the counter words of the last host-form render
   unsigned long long *d_counters = nullptr;
@@ -342,10 +343,66 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
 // that passes the mesh's own AABB test, whatever their box (a duplicate test cannot change the
 // lexicographic minimum of (t, file index)).  More than CTR_GUARD_SLOTS of them: every node of the mesh
 // gets unbounded boxes instead — the reference's linear walk through the same code.
-// (Not covered: a secondary ray that falls into a triangle's plane by coincidence of a reflection.)
+// Secondary rays (round 3; tests/test_gpu_parity.py::test_secondary_rays_coplanar_with_triangles showed the hole is real:
+// one pixel of a purpose-built scene differed).  A ray reflected by a PLANAR mirror lies on the line through the
+// mirror image of its parent's origin, so the rays a flat mirror makes of the primary rays all pass through the
+// mirror image of the eye — a VIRTUAL eye — and fall into a triangle's plane only if that point lies in it.  The
+// same check therefore runs for the virtual eyes too: every eye mirrored in every reflective plane, stand-alone
+// triangle and triangle of a small mesh (<= CTR_MIRROR_MESH_TRIS: mirrors built from a few triangles, like
+// scene/mirror.stl), and those images mirrored once more (reflections of reflections) while the list stays short.
+// Pass-through rays continue their parent's line and need no entry; shadow rays run from a surface to a light, whose
+// position is checked already; a sphere keeps a pencil of rays planar only in a plane through its centre and the
+// pencil's apex, which the apex's own entry covers.  NOT covered: chains of more than two reflections, mirrors that
+// are large meshes, and single rays (not families) that meet a triangle's plane by numerical coincidence — per (ray,
+// triangle) pair a ~1e-9 event that no full-size comparison or fuzz run has shown yet.
 #define CTR_GUARD_SLOTS 64u
+#define CTR_MIRROR_MESH_TRIS 16u
+#define CTR_VIRTUAL_EYES_MAX 96u
 int refresh_linear_meshes(ctr_scene *s) {
   constexpr double TOL = 1.0 / 131072.0;
+  // ---- the points a family of rays can emanate from: eyes, and their images in the scene's flat mirrors ----
+  struct P3 { double x, y, z; };
+  struct Mirror { P3 p, n; };  // a point of the plane, its unit normal
+  std::vector<Mirror> mirrors;
+  auto add_mirror = [&](double px, double py, double pz, double nx, double ny, double nz) {
+    const double len = sqrt(nx * nx + ny * ny + nz * nz);
+    if (!(len > 0.0)) return;
+    nx /= len; ny /= len; nz /= len;
+    const double c = px * nx + py * ny + pz * nz;
+    for (const Mirror &m : mirrors) {  // one entry per plane (a mirror made of coplanar triangles)
+      const double dot = m.n.x * nx + m.n.y * ny + m.n.z * nz, cm = m.p.x * m.n.x + m.p.y * m.n.y + m.p.z * m.n.z;
+      if ((fabs(dot - 1.0) < 1e-9 && fabs(cm - c) < 1e-9 * (1.0 + fabs(c))) || (fabs(dot + 1.0) < 1e-9 && fabs(cm + c) < 1e-9 * (1.0 + fabs(c)))) return;
+    }
+    mirrors.push_back({{px, py, pz}, {nx, ny, nz}});
+  };
+  auto tri_plane = [&](const DTri &T) {
+    const double ax = T.ab[0][0], ay = T.ab[1][0], az = T.ab[2][0], bx = T.ab[0][1], by = T.ab[1][1], bz = T.ab[2][1];
+    add_mirror(T.px, T.py, T.pz, ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx);
+  };
+  for (const DObj &O : s->h_objs) {
+    if (O.mat >= s->h_mats.size() || !((double)s->h_mats[O.mat].reflexivity >= 1e-6)) continue;
+    if (O.type == CTR_OBJ_PLANE) add_mirror(O.f[0], O.f[1], O.f[2], O.f[3], O.f[4], O.f[5]);
+    else if (O.type == CTR_OBJ_TRIANGLE) tri_plane(s->h_tris[O.tri_begin]);
+    else if (O.type == CTR_OBJ_MESH && O.tri_count <= CTR_MIRROR_MESH_TRIS)
+      for (uint32_t k = 0; k < O.tri_count; k++) tri_plane(s->h_tris[O.tri_begin + k]);
+  }
+  std::vector<P3> origins;
+  for (const DCam &c : s->h_cams) origins.push_back({c.pos[0], c.pos[1], c.pos[2]});
+  {
+    auto image = [](const P3 &e, const Mirror &m) {
+      const double d = (e.x - m.p.x) * m.n.x + (e.y - m.p.y) * m.n.y + (e.z - m.p.z) * m.n.z;
+      return P3{e.x - 2.0 * d * m.n.x, e.y - 2.0 * d * m.n.y, e.z - 2.0 * d * m.n.z};
+    };
+    const size_t n_eyes = origins.size();
+    std::vector<std::pair<P3, size_t>> first;  // image, the mirror that made it
+    for (size_t e = 0; e < n_eyes && first.size() < CTR_VIRTUAL_EYES_MAX; e++)
+      for (size_t m = 0; m < mirrors.size() && first.size() < CTR_VIRTUAL_EYES_MAX; m++) first.push_back({image(origins[e], mirrors[m]), m});
+    for (const auto &f : first) origins.push_back(f.first);
+    if (first.size() * (mirrors.size() ? mirrors.size() - 1 : 0) + origins.size() <= CTR_VIRTUAL_EYES_MAX)
+      for (const auto &f : first)
+        for (size_t m = 0; m < mirrors.size(); m++)
+          if (m != f.second) origins.push_back(image(f.first, mirrors[m]));
+  }
   for (ctr_scene::MeshGuard &g : s->guards) {
     if (g.mesh_pos < 0) continue;
     std::vector<uint32_t> risky;
@@ -360,8 +417,8 @@ int refresh_linear_meshes(ctr_scene *s) {
         return dist <= TOL * scale;
       };
       bool hit = false;
-      for (const DCam &c : s->h_cams)
-        if (point_in_plane(c.pos[0], c.pos[1], c.pos[2])) hit = true;
+      for (const P3 &o : origins)
+        if (point_in_plane(o.x, o.y, o.z)) hit = true;
       for (const DLight &l : s->h_lights) {
         if (l.type == CTR_LIGHT_POINT) {
           if (point_in_plane(l.vx, l.vy, l.vz)) hit = true;
@@ -716,6 +773,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->h_meshes = meshes;
   s->h_cams.assign(1, s->cam);
   s->h_lights = lights;
+  s->h_mats = mats;
   if (int st = refresh_linear_meshes(s)) {
     ctr_scene_destroy(s);
     return st;

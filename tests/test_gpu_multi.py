@@ -251,3 +251,25 @@ def test_group_grows_then_renders(ca):
             s.set_size(w, h)
             assert _same(m.render(bounces=3), ca.DeviceScene(s).render(bounces=3)), (transport, w, h)
         m.close()
+
+
+def test_bench_c4_strong_two_ranks_on_one_gpu(ca):
+    """bench.py --workload c4 --scaling strong --roots rank0 --check as the driver would launch it on 2 GPUs, rehearsed on
+    the one GPU there is (both ranks on device 0, gloo standing in for RCCL, which refuses one device twice): one frame
+    of the 4x4 grid per step, row-tiled over the ranks, gathered to rank 0, every gathered frame bitwise the
+    single-process render; the JSON line carries the strong-scaling workload."""
+    import json
+    import socket
+    import sys
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, CUTRACE_BENCH_SHARE_GPU="1", CUTRACE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "c4", "--scaling", "strong", "--roots", "rank0", "--width", "512", "--height", "512", "--check",
+           "--skip-probe", "--no-extras"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "gathered frame(s) bitwise equal" in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["frames_per_step"] == 1
+    assert "bunny_grid4x4.json@512x512" in line["config"]["workload"] and "gather to rank 0" in line["config"]["workload"]

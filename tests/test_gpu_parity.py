@@ -466,6 +466,90 @@ def test_rays_coplanar_with_triangles(ca, tmp_path, seed):
     assert fast["ray_count"] == plain["ray_count"] == o["ray_count"]
 
 
+def _mirror_coplanar_scene(ca, tmp_path, w, h, row, n_tris, seed, transparent, two_mirrors=False):
+    """The same regime for SECONDARY rays, which no upload-time guard can see (ctr_api.cpp refresh_linear_meshes checks eyes
+    and lights): a tilted mirror reflects every primary ray of image row `row` into ONE plane — the mirror image of the
+    row's plane, through the mirror image of the eye — and the mesh's triangles lie in that plane to float rounding, some
+    on the reflected rays' way, some far to the side of it.  For those reflected rays (and, with `transparent`, for the
+    pass-through rays that continue from an in-plane hit in the same plane) alpha and all three numerators of
+    default_schema.hpp:57-78 are rounding noise.  Neither the eye nor any light lies in that plane."""
+    import ctypes as C
+    import json
+    from cutrace_amd import _lib, scenes
+    rng = np.random.default_rng(seed)
+    eye, up, look = (0.2, 0.9, 3.5), (0.0, 1.0, 0.0), (0.02, -0.1, -1.0)
+    cam = _lib.Camera()
+    _lib.host_lib().ctr_camera_look_at(C.byref(cam), _lib.Vec3(*eye), _lib.Vec3(*up), _lib.Vec3(*look))
+    f32, f64 = np.float32, np.float64
+    E, R, U, F = (np.array(v.tup(), f64) for v in (cam.pos, cam.right, cam.up, cam.forward))
+    v = (0.5 - row / h) * U + F                           # the row's rays: E + s*R + t*v
+    pm = np.array([0.0, 0.0, -2.0])                       # the mirror: a plane through pm, tilted towards the ceiling
+    nm = np.array([0.0, 0.35, 1.0])
+    mirrors = [(pm, nm)]
+    if two_mirrors:                                       # ... and a second one above that sends the rays down again
+        mirrors.append((np.array([0.0, 3.0, 0.0]), np.array([0.0, -1.0, 0.25])))
+    E2, R2, v2, t_mirror = E, R, v, 0.0
+    for (p_, n_) in mirrors:                              # images of the eye and of the row's plane, mirror after mirror
+        nh = n_ / np.linalg.norm(n_)
+        t_mirror = np.dot(p_ - E2, nh) / np.dot(v2, nh)   # where the row's central ray meets this mirror
+        assert t_mirror > 0
+        E2 = E2 - 2.0 * np.dot(E2 - p_, nh) * nh
+        R2, v2 = R2 - 2.0 * np.dot(R2, nh) * nh, v2 - 2.0 * np.dot(v2, nh) * nh
+    tris = []
+    for _ in range(n_tris):
+        s0, t0 = rng.uniform(-1.5, 1.5), t_mirror + rng.uniform(0.4, 3.5)   # beyond the mirror point = on the reflected side
+        pts = []
+        for _ in range(3):
+            s_, t_ = s0 + rng.uniform(-0.3, 0.3), t0 + rng.uniform(-0.35, 0.35)
+            pts.append((E2 + s_ * R2 + t_ * v2).astype(f32))
+        tris.append(pts)
+    stl = str(tmp_path / f"mirror_coplanar_{seed}_{int(transparent)}.stl")
+    scenes.write_stl(stl, np.asarray(tris, f32))
+    mesh_mat = {"type": "solid", "color": [0.8, 0.6, 0.3], "specular": 0.4, "reflect": 0.3, "phong": 40}
+    if transparent:
+        mesh_mat["transparency"] = 0.4
+    sc = {"camera": {"eye": list(eye), "up": list(up), "look": list(look), "near_plane": 0.1, "far_plane": 100.0,
+                     "width": w, "height": h, "ambient": 0.1},
+          "lights": [{"type": "point", "point": [1.5, 2.5, 2.0], "color": [0.8, 0.8, 0.8]},
+                     {"type": "sun", "direction": [0.3, -1.0, -0.2], "color": [0.4, 0.4, 0.4]}],
+          "materials": [mesh_mat,
+                        {"type": "solid", "color": [0.3, 0.5, 0.9], "specular": 0.2, "reflect": 0.0, "phong": 10},
+                        {"type": "solid", "color": [0.9, 0.9, 0.9], "specular": 0.1, "reflect": 0.9, "phong": 20}],
+          "objects": [{"type": "mesh", "file": stl, "material": 0},
+                      {"type": "plane", "point": [0, -1.5, 0], "normal": [0, 1, 0], "material": 1}] +
+                     [{"type": "plane", "point": [float(x) for x in p_], "normal": [float(x) for x in n_], "material": 2}
+                      for (p_, n_) in mirrors]}
+    s = ca.HostScene.parse(json.dumps(sc))
+    assert s.ok
+    return s
+
+
+@pytest.mark.parametrize("seed,transparent,two_mirrors", [(1, False, False), (2, False, False), (3, False, False), (4, True, False),
+                                                          (5, True, False), (6, False, True), (7, False, True), (8, True, True)])
+def test_secondary_rays_coplanar_with_triangles(ca, tmp_path, seed, transparent, two_mirrors):
+    """reflected (and passed-through) rays that fall into the plane of mesh triangles by construction —
+    after one flat mirror, or (two_mirrors) after a mirror and a second mirror.  Without the virtual-eye guard
+    (ctr_api.cpp refresh_linear_meshes) seed 2 differed from the linear walk in one pixel.  The accelerated kernel (BVH culling, prefilter, any-hit where all materials are opaque) must equal the plain linear
+    walk — the reference's own traversal — bit for bit, and the oracle within the parity bar."""
+    w, h, row = 384, 32, 9
+    s = _mirror_coplanar_scene(ca, tmp_path, w, h, row, 40, seed, transparent, two_mirrors)
+    o = oracle.oracle_render(s, bounces=3, threads=os.cpu_count() or 4)
+    ds = ca.DeviceScene(s)
+    ds.set_variant(ca.VAR_EXACT_POW)
+    fast = ds.render(bounces=3)
+    ds.set_variant(ca.VAR_EXACT_POW | ca.VAR_NO_CLUSTER | ca.VAR_NO_PREFILTER | ca.VAR_NO_ANYHIT)
+    plain = ds.render(bounces=3)
+    assert_parity(plain, o, what=f"mirror-coplanar seed {seed}: plain walk vs oracle")
+    on_mirror = int((o["hit_id"][row] == 2).sum())
+    diff = int((fast["color"].view(np.uint32) != plain["color"].view(np.uint32)).any(axis=-1).sum())
+    print(f"mirror-coplanar seed {seed} transparent={transparent}: {on_mirror} of {w} pixels of row {row} see the mirror; "
+          f"accelerated vs plain: {diff} pixels differ in colour")
+    assert on_mirror > w // 2
+    for k in ("depth", "normal", "color"):
+        assert same_bits(fast[k], plain[k]), f"seed {seed}: {k}"
+    assert fast["ray_count"] == plain["ray_count"] == o["ray_count"]
+
+
 def test_exact_sqrt_and_reciprocal_shortcut_is_exhaustively_correct(ca):
     """The kernel normalises vectors with a shorter instruction sequence than hipcc's correctly rounded sqrtf and
     division (render_kernel.hip norm_and_inverse); it must give the same bits for EVERY mantissa."""

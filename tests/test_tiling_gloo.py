@@ -24,14 +24,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, frames, steps, roots, out_dir):
+def _scene(ca, out_dir, which):
+    if which == "c4":  # BASELINE config 5's scene (16 translated bunnies in one room), as bench.py --workload c4 generates it
+        from cutrace_amd import scenes
+        return ca.HostScene.load(scenes.make_bunny_grid(os.path.join(out_dir, "c4_scene")))
+    return ca.HostScene.load("scene/sphere_plane.json")
+
+
+def _worker(rank, world, port, w, h, frames, steps, roots, out_dir, which="sphere_plane"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import cutrace_amd as ca
     from cutrace_amd.tiling import FrameTiler
-    s = ca.HostScene.load("scene/sphere_plane.json")
+    s = _scene(ca, os.path.join(out_dir, f"rank{rank}"), which)
     s.set_size(w, h)
     tiler = FrameTiler(w, h, frames, rank, world, "cpu", roots=roots)
     total_rays = 0
@@ -87,6 +94,22 @@ def test_gather_reassembles_frames(ca, tmp_path, world, h, frames, roots):
         for f in range(frames):
             rays += oracle.oracle_render(s, bounces=2 + f, fudge=1e-3 * (1 + step), threads=4)["ray_count"]
     assert total == rays
+
+
+def test_c4_strong_mode_world_two(ca, tmp_path):
+    """bench.py --workload c4 --scaling strong --roots rank0 on two gloo ranks: ONE frame of the 4x4 bunny grid per step,
+    interleaved 8-row blocks over the ranks, gathered to rank 0 — bitwise the single-process frame (oracle as renderer,
+    small image: the reference's flat walk over 16 000 triangles is slow)."""
+    w, h, steps, world = 24, 20, 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), w, h, 1, steps, "rank0", str(tmp_path), "c4"), nprocs=world, join=True)
+    s = _scene(ca, str(tmp_path / "check"), "c4")
+    s.set_size(w, h)
+    assert not (tmp_path / "final_rank1.npz").exists()
+    got = np.load(tmp_path / "final_rank0.npz")
+    assert list(got["frames"]) == [0]
+    full = oracle.oracle_render(s, bounces=2, fudge=1e-3 * steps, threads=4)
+    for k in ("depth", "color", "normal"):
+        assert np.array_equal(got[k][0].view(np.uint32), full[k].view(np.uint32)), k
 
 
 def test_partition_covers_every_row_once():
