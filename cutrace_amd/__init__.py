@@ -188,6 +188,23 @@ class DeviceScene:
                     kernel_ms=stats.kernel_ms, total_ms=stats.total_ms, max_depth=float(stats.max_depth),
                     rows=int(stats.rows))
 
+    def render_uv(self, fudge=1e-3, bounces=5, rows=None):
+        """ctr_render_uv: the three buffers plus `uv` (n, w, 2): ray_cast's texture coordinates of the primary hit."""
+        L = _lib.hip_lib()
+        r = make_rows(self.h, rows)
+        n = rows_count(self.h, rows)
+        depth = np.empty((n, self.w), np.float32)
+        color = np.empty((n, self.w, 3), np.float32)
+        normal = np.empty((n, self.w, 3), np.float32)
+        uv = np.empty((n, self.w, 2), np.float32)
+        stats = RenderStats()
+        st = L.ctr_render_uv(self._h, C.c_float(fudge), bounces, C.byref(r), depth.ctypes.data, color.ctypes.data,
+                             normal.ctypes.data, uv.ctypes.data, C.byref(stats))
+        if st:
+            raise RuntimeError(f"ctr_render_uv failed ({st}): {L.ctr_last_error().decode()}")
+        return dict(depth=depth, color=color, normal=normal, uv=uv, ray_count=int(stats.ray_count),
+                    kernel_ms=stats.kernel_ms, total_ms=stats.total_ms, max_depth=float(stats.max_depth), rows=int(stats.rows))
+
     def render_device(self, d_depth, d_color, d_normal, d_counters=0, stream=0, fudge=1e-3, bounces=5, rows=None):
         """Device-buffer form (ctr_render_device): raw device pointers, async on `stream`."""
         L = _lib.hip_lib()

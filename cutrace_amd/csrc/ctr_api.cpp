@@ -136,6 +136,8 @@ struct ctr_scene {
   // cached device outputs for the host-buffer form: ONE allocation, a call's buffers are its consecutive
   // parts [depth px | color 3 px | normal 3 px] so that a frame can leave in a single D2H transfer
   float *d_out = nullptr;
+  float *d_uv = nullptr;      // ctr_render_uv: 2 floats per pixel, allocated on first use
+  size_t uv_px = 0;
   // Guard of the BVH culling (see refresh_linear_meshes): host copies of what it needs
   struct MeshGuard {
     uint32_t node_begin = 0, node_count = 0;
@@ -582,6 +584,8 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         tris.emplace_back();
         gn.resize(4 * tris.size());
         make_tri(o.v0, o.v1, o.v2, 0, tris.back(), &gn[4 * (tris.size() - 1)]);
+        O.f[0] = o.v0.x; O.f[1] = o.v0.y; O.f[2] = o.v0.z;  // p1, p3: triangle::uv_for (KV_UV)
+        O.f[3] = o.v2.x; O.f[4] = o.v2.y; O.f[5] = o.v2.z;
         break;
       }
       case CTR_OBJ_MESH: {
@@ -811,7 +815,7 @@ void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_nodes4, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
-                  (void *)s->d_out, (void *)s->d_groups, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
+                  (void *)s->d_out, (void *)s->d_uv, (void *)s->d_groups, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
     if (p) (void)hipFree(p);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
   if (s->h_groups) (void)hipHostFree(s->h_groups);
@@ -904,7 +908,7 @@ int ctr_render_device(ctr_scene *s, float fudge, int bounces, const ctr_rows *ro
 }
 
 static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,
-                       float *normal3, ctr_render_stats *stats, bool count, unsigned long long *aabb_tris) {
+                       float *normal3, ctr_render_stats *stats, bool count, unsigned long long *aabb_tris, float *uv2 = nullptr) {
   auto t0 = std::chrono::high_resolution_clock::now();
   int st = check_args(s, bounces);
   if (st) return st;
@@ -919,7 +923,7 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   // "Host delivery"), so the 28 bytes per pixel cross PCIe underneath the rendering instead of in a DMA after it.
   // Any other destination: device buffers + copies, below.
   float *zd = nullptr, *zc = nullptr, *zn = nullptr;
-  const bool direct = px && depth && color3 && normal3 && !count && !(s->user_variant & (CTR_VAR_NO_DIRECT | CTR_VAR_STATS)) &&
+  const bool direct = px && depth && color3 && normal3 && !count && !uv2 && !(s->user_variant & (CTR_VAR_NO_DIRECT | CTR_VAR_STATS)) &&
                       ctr_host_delivery_available(s->kernel_variant(false)) &&
                       is_pinned(depth) && is_pinned(depth + px - 1) && is_pinned(color3) && is_pinned(color3 + 3 * px - 1) &&
                       is_pinned(normal3) && is_pinned(normal3 + 3 * px - 1) && device_view(depth, &zd) &&
@@ -953,6 +957,18 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   }
   L.counters = s->d_counters;
   L.variant = s->kernel_variant(count);
+  if (uv2 && px) {
+    if (count || (s->user_variant & CTR_VAR_STATS)) return fail(CTR_E_INVALID, "ctr_render_uv: not with the counting / statistics variants");
+    if (px > s->uv_px) {
+      if (s->d_uv) (void)hipFree(s->d_uv);
+      s->d_uv = nullptr;
+      s->uv_px = 0;
+      HIP_TRY(hipMalloc((void **)&s->d_uv, sizeof(float) * 2 * px));
+      s->uv_px = px;
+    }
+    L.uv = s->d_uv;
+    L.variant = (L.variant & (KV_ANYHIT | KV_FASTPOW)) | KV_PREFILTER | KV_BVH | KV_UV;
+  }
   if ((st = attach_order(s, L, count))) return st;
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), nullptr));
   HIP_TRY(hipEventRecord(s->ev0, nullptr));
@@ -977,6 +993,7 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
       HIP_TRY(out(color3, L.color, 3 * px));
       HIP_TRY(out(normal3, L.normal, 3 * px));
     }
+    if (uv2) HIP_TRY(hipMemcpy(uv2, s->d_uv, sizeof(float) * 2 * px, hipMemcpyDeviceToHost));
   }
   HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, nullptr));
   const size_t n_groups = direct ? (size_t)ctr_staging_groups(L) : 0;
@@ -1048,6 +1065,12 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
 int ctr_render(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,
                float *normal3, ctr_render_stats *stats) {
   return render_host(s, fudge, bounces, rows, depth, color3, normal3, stats, false, nullptr);
+}
+
+int ctr_render_uv(ctr_scene *s, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,
+                  float *normal3, float *uv2, ctr_render_stats *stats) {
+  if (!uv2) return fail(CTR_E_INVALID, "ctr_render_uv: null uv buffer");
+  return render_host(s, fudge, bounces, rows, depth, color3, normal3, stats, false, nullptr, uv2);
 }
 
 int ctr_debug_poison_next_order(ctr_scene *s) {

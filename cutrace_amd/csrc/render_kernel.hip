@@ -282,6 +282,7 @@ struct KArgs {
   // "Host delivery" (below): null group_done = the outputs are written in place
   float *host_depth, *host_color, *host_normal;
   uint32_t *group_done;
+  float *uv_out;      // KV_UV: texture coordinates of the primary hit, 2 floats per pixel
 };
 
 // ---- Host delivery ----
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 #endif
   constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
   constexpr bool HOSTOUT = (KV & KV_HOSTOUT) != 0;  // "Host delivery"
+  constexpr bool UV = (KV & KV_UV) != 0;            // ray_cast's tex_coords of the primary cast as a fourth output
   // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast,
   // and how many of the 64 lanes had a use for the wave-level work: [6] lanes whose ray meets one of the
@@ -1169,6 +1171,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     if (MSP_IS_RADIANCE(msp)) {
       // ---- hit record: hit point, normal (per primitive), material ----
       V3 normal = mk(0, 0, 0);
+      float tc_u = 0.0f, tc_v = 0.0f;  // (UV) uv{} of kernel.hpp:51 on a miss
       if (was_hit) {
         const CADDR DObj &H = AK->objs[bobj];
         CTR_MARK(37);  // hit record
@@ -1185,12 +1188,37 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           const V3 hit = vadd(ro, vscale(hit_dn, best));
           normal = vnormalized(vsub(hit, mk(H.f[0], H.f[1], H.f[2])));
           ro = hit;
+          if (UV && first_trip) {  // default_schema.hpp:246-249: delta = (hit - center).normalized() is the normal again
+            tc_u = 0.5f + (atan2f(normal.z, normal.x) / (2.0f * (float)M_PI));
+            tc_v = 0.5f + (asinf(normal.y) / (float)M_PI);
+          }
         } else if (ht == CTR_OBJ_PLANE) {
           ro = pos;
           normal = mk(H.f[3], H.f[4], H.f[5]);
+          if (UV && first_trip) {  // plane::uv_for, default_schema.hpp:169-178
+            const V3 ax1 = vnormalized(mk(normal.y, -normal.x, 0.0f));
+            const V3 ax2 = vcross(normal, ax1);
+            const V3 mod_pt = vsub(mk(H.f[0], H.f[1], H.f[2]), pos);
+            tc_u = vdot(ax1, mod_pt);
+            tc_v = vdot(ax2, mod_pt);
+          }
         } else {
           ro = pos;
           normal = mk(AK->gnorm[4 * btri + 0], AK->gnorm[4 * btri + 1], AK->gnorm[4 * btri + 2]);
+          if (UV && first_trip) {
+            if (ht == CTR_OBJ_MESH) {  // mesh::intersect, default_schema.hpp:138-139
+              tc_u = pos.x;
+              tc_v = pos.y;
+            } else {                   // triangle::uv_for, default_schema.hpp:37-46
+              const CADDR DTri &T = A.tris[btri];
+              const V3 p1 = mk(H.f[0], H.f[1], H.f[2]), p2 = mk(T.px, T.py, T.pz), p3 = mk(H.f[3], H.f[4], H.f[5]);
+              const V3 p2p1 = vsub(p2, p1), p3p1 = vsub(p3, p1), xp1 = vsub(pos, p1);
+              const V3 proj_u = vscale(p2p1, vdot(xp1, p2p1) / vdot(p2p1, p2p1));
+              const V3 proj_v = vscale(p3p1, vdot(xp1, p3p1) / vdot(p3p1, p3p1));
+              tc_u = vnorm(proj_u) / vnorm(p2p1);
+              tc_v = vnorm(proj_v) / vnorm(p3p1);
+            }
+          }
         }
       }
       CTR_MARK(39);
@@ -1201,6 +1229,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         if (HOSTOUT) __hip_atomic_store(depth_out + px_id, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else depth_out[px_id] = best;
         store3(normal_out, px_id, normal);
+        if (UV) {
+          float *const uvp = AK->uv_out;
+          uvp[2 * px_id + 0] = tc_u;
+          uvp[2 * px_id + 1] = tc_v;
+        }
         first_depth = best;
       }
       CTR_MARK(41);
@@ -1794,6 +1827,8 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.host_color = L.host_color;
   A.host_normal = L.host_normal;
   A.group_done = L.group_done;
+  A.uv_out = L.uv;
+  if (((KV & KV_UV) != 0) != (L.uv != nullptr)) return (int)hipErrorInvalidValue;
   size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
   if (KV & KV_OCC6) lds_bytes += (size_t)WAVES_PER_WG * 5 * 64 * sizeof(float);  // PARK
   // diagnostic only: extra dynamic LDS per workgroup caps the waves resident per CU (occupancy sweeps)
@@ -1912,6 +1947,11 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
     if (!(L.variant & KV_ANYHIT)) return launch<DEF>(L, s);
     if ((L.variant & KV_OCC6) && occ6_fits(sb)) return launch<DEF | KV_ANYHIT | KV_OCC6>(L, s);
     return launch<DEF | KV_ANYHIT>(L, s);
+  }
+  if (L.variant & KV_UV) {  // the fourth output: the shipped walk only (BVH + prefilter), any-hit and pow as the scene / caller say
+    constexpr uint32_t U = KV_PREFILTER | KV_BVH | KV_UV;
+    if (L.variant & KV_FASTPOW) return (L.variant & KV_ANYHIT) ? launch<U | KV_FASTPOW | KV_ANYHIT>(L, s) : launch<U | KV_FASTPOW>(L, s);
+    return (L.variant & KV_ANYHIT) ? launch<U | KV_ANYHIT>(L, s) : launch<U>(L, s);
   }
   if (L.variant & KV_COUNT) return launch<KV_PREFILTER | KV_COUNT>(L, s);
   if (L.variant & KV_STATS)

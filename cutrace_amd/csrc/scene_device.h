@@ -50,7 +50,7 @@ struct DObj {
                         // to its GUARD records (triangles every lane that enters the mesh must meet, whatever their
                         // box; ctr_api.cpp refresh_linear_meshes) and then to the root
   uint32_t index;       // position in the scene's object list (hit_id; ties on t go to the lower index)
-  // triangle: unused
+  // triangle: f[0..2] p1, f[3..5] p3 (p2 is in its DTri): triangle::uv_for needs the vertices themselves (KV_UV only)
   // mesh    : f[0..2] bbox.min, f[3..5] bbox.max
   // plane   : f[0..2] point,    f[3..5] normal
   // sphere  : f[0..2] center,   f[3] radius, f[4] radius*radius
@@ -104,6 +104,7 @@ enum : uint32_t {
   KV_FASTPOW = 32u,    // specular pow() as exp2(e*log2(x)) in f32 instead of f64 pow
   KV_OCC6 = 64u,       // compiled for 6 waves per SIMD instead of 5 (large meshes: latency-bound on scalar-cache misses)
   KV_HOSTOUT = 128u,   // the launch delivers the frame to page-locked host memory itself (RenderLaunch::group_done)
+  KV_UV = 256u,        // also write the texture coordinates of the primary hit (ray_cast's tex_coords), RenderLaunch::uv
 };
 
 struct DRows {
@@ -144,6 +145,7 @@ struct RenderLaunch {
   float *depth;
   float *color;
   float *normal;
+  float *uv;                     // KV_UV: 2 floats per pixel (same indexing as depth), else null
   unsigned long long *shards;    // scene-owned CTR_SHARDS x CTR_SHARD_WORDS scratch the kernel adds into
   unsigned long long *counters;  // [0] ray_count, [1] max-depth bits, [2] AABB-hit triangle count (KV_COUNT), [4..9] KV_STATS
   uint32_t variant;

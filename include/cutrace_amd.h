@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 2   /* 2 (round 3): CTR_E_DELIVERY, ctr_multi_submit / ctr_multi_wait, ctr_set_variant rejects unknown bits
+#define CTR_ABI_VERSION 2   /* 2 (round 3): CTR_E_DELIVERY, ctr_multi_submit / ctr_multi_wait, ctr_render_uv, ctr_set_variant rejects unknown bits
                              * (1 silently ignored the bits CTR_VAR_TRI_LDS = 1, CTR_VAR_VMEM = 64, CTR_VAR_SMEM = 128 that round 2 removed) */
 
 /* ---- status codes ------------------------------------------------------- */
@@ -287,6 +287,14 @@ int ctr_selftest_exact_math(uint64_t *n_mismatch);
  * [13] / [14]: per mesh entry the largest number of node visits / triangle tests any ONE lane had a use for, summed —
  * what a walk by every lane for itself would take in wave steps (the bound on a per-lane walk). */
 int ctr_last_counters(ctr_scene *scene, uint64_t *out16);
+/* ctr_render plus a FOURTH output: the texture coordinates ray_cast hands back for the primary hit (its tex_coords,
+ * inc/ray_cast.hpp:47 — triangle::uv_for, plane::uv_for, the sphere's atan2 / asin pair, a mesh's (hit.x, hit.y);
+ * inc/default_schema.hpp:37-46,138-139,169-178,246-249), uv2 = 2 floats per pixel, row-major like depth, (0, 0) on a
+ * miss.  The reference computes them for every cast and uses them nowhere (its only material ignores them,
+ * :326-340); a material that reads them would start from here.  The frame leaves through device
+ * buffers and copies (no delivery by the kernel); depth / colour / normal are bit-identical to ctr_render's. */
+int ctr_render_uv(ctr_scene *scene, float fudge, int bounces, const ctr_rows *rows, float *depth, float *color3,
+                  float *normal3, float *uv2, ctr_render_stats *stats);
 /* Test hook: the next launch on this handle gets a dispatch order whose second half names no tile, i.e. it renders
  * half the tiles and leaves the rest untouched.  A ctr_render that delivers the frame itself then fails with
  * CTR_E_DELIVERY; the handle stays usable (tests/test_gpu_parity.py). */

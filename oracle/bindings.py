@@ -12,9 +12,9 @@ _oracle = None
 _ref = None
 
 
-def _render_sig(fn):
+def _render_sig(fn, uv=False):
     fn.argtypes = [C.POINTER(_lib.SceneDesc), C.c_float, C.c_int, C.POINTER(_lib.Rows), C.c_int, C.c_void_p,
-                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + ([C.c_void_p] if uv else [])
     fn.restype = C.c_int
 
 
@@ -26,6 +26,7 @@ def oracle_lib():
             raise RuntimeError(f"{path} missing: run `make -C oracle oracle`")
         L = C.CDLL(path)
         _render_sig(L.orc_render)
+        _render_sig(L.orc_render_uv, uv=True)
         L.orc_look_at.argtypes = [C.POINTER(_lib.Camera), _lib.Vec3, _lib.Vec3, _lib.Vec3]
         L.orc_quantise_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
         L.orc_quantise_normal.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
@@ -44,6 +45,8 @@ def ref_lib():
             return None
         L = C.CDLL(path)
         _render_sig(L.ref_render)
+        if hasattr(L, "ref_render_uv"):
+            _render_sig(L.ref_render_uv, uv=True)
         L.ref_look_at.argtypes = [C.POINTER(_lib.Camera), _lib.Vec3, _lib.Vec3, _lib.Vec3]
         _ref = L
     return _ref
@@ -73,7 +76,7 @@ def ref_cudaminmax_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hi
     return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)
 
 
-def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids):
+def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids, want_uv=False):
     w, h = scene.size
     r = make_rows(h, rows)
     n = rows_count(h, rows)
@@ -82,22 +85,27 @@ def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids):
     normal = np.empty((n, w, 3), np.float32)
     hit = np.empty((n, w), np.int64) if want_hit_ids else None
     counters = (C.c_uint64 * 2)()
-    st = fn(scene.desc, C.c_float(fudge), bounces, C.byref(r), threads, depth.ctypes.data, color.ctypes.data,
-            normal.ctypes.data, hit.ctypes.data if hit is not None else None, counters)
+    uv = np.empty((n, w, 2), np.float32) if want_uv else None
+    args = [scene.desc, C.c_float(fudge), bounces, C.byref(r), threads, depth.ctypes.data, color.ctypes.data,
+            normal.ctypes.data, hit.ctypes.data if hit is not None else None, counters]
+    if want_uv:
+        args.append(uv.ctypes.data)
+    st = fn(*args)
     if st:
         raise RuntimeError(f"cpu render failed: {st}")
     return dict(depth=depth, color=color, normal=normal, hit_id=hit, ray_count=int(counters[0]),
-                alg_bytes=int(counters[1]))
+                alg_bytes=int(counters[1]), uv=uv)
 
 
-def oracle_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
-    """CPU restatement (oracle/ctr_oracle.c)."""
-    return _cpu_render(oracle_lib().orc_render, scene, fudge, bounces, rows, threads, hit_ids)
+def oracle_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True, uv=False):
+    """CPU restatement (oracle/ctr_oracle.c).  uv=True: also the texture coordinates of the primary hit."""
+    L = oracle_lib()
+    return _cpu_render(L.orc_render_uv if uv else L.orc_render, scene, fudge, bounces, rows, threads, hit_ids, uv)
 
 
-def ref_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
+def ref_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True, uv=False):
     """The reference's own headers compiled for the host (oracle/_ref)."""
     L = ref_lib()
     if L is None:
         raise RuntimeError("oracle/_ref/libcutrace_ref.so not built (needs /root/reference)")
-    return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)
+    return _cpu_render(L.ref_render_uv if uv else L.ref_render, scene, fudge, bounces, rows, threads, hit_ids, uv)

@@ -74,6 +74,7 @@ typedef struct {
   uint64_t alg_bytes;   /* SURVEY §8(d) algorithmic bytes of those casts */
   int trace;            /* debugging aid: print every cast (orc_trace_pixel) */
   int64_t last_tri;     /* index (within the mesh) of the triangle that won the last mesh_intersect */
+  float *uv;            /* optional output: texture coordinates of the primary hit, 2 floats per pixel */
 } octx;
 
 /* ---- inc/default_schema.hpp primitives ------------------------------------ */
@@ -294,6 +295,41 @@ static ray cam_get_ray(const ctr_camera *cam, uint64_t x, uint64_t y) {
   return r;
 }
 
+/* Texture coordinates of a hit (ray_cast's tex_coords, ray_cast.hpp:47).  Every primitive computes them from the hit
+ * point alone, so they are restated as a function of the winning object and its hit point:
+ *   triangle::uv_for  default_schema.hpp:37-46     plane::uv_for  :169-178
+ *   sphere            :246-249 (delta = (hit - center).normalized(), atan2 / asin)
+ *   mesh              :138-139 (u = hit.x, v = hit.y)
+ * A miss leaves the value-initialised uv{} of kernel.hpp:51: (0, 0). */
+static void uv_of_hit(const ctr_object *o, vec hit, float *u, float *v) {
+  switch (o->type) {
+    case CTR_OBJ_TRIANGLE: {
+      vec p2p1 = vsub(o->v1, o->v0), p3p1 = vsub(o->v2, o->v0), xp1 = vsub(hit, o->v0);
+      vec proj_u = vscale(p2p1, vdot(xp1, p2p1) / vdot(p2p1, p2p1));
+      vec proj_v = vscale(p3p1, vdot(xp1, p3p1) / vdot(p3p1, p3p1));
+      *u = vnorm(proj_u) / vnorm(p2p1);
+      *v = vnorm(proj_v) / vnorm(p3p1);
+      break;
+    }
+    case CTR_OBJ_MESH: *u = hit.x; *v = hit.y; break;
+    case CTR_OBJ_PLANE: {
+      vec normal = o->v1;
+      vec ax1 = vnormalized(v3(normal.y, -normal.x, 0.0f));
+      vec ax2 = vcross(normal, ax1);
+      vec mod_pt = vsub(o->v0, hit);
+      *u = vdot(ax1, mod_pt);
+      *v = vdot(ax2, mod_pt);
+      break;
+    }
+    default: {
+      vec delta = vnormalized(vsub(hit, o->v0));
+      *u = 0.5f + (atan2f(delta.z, delta.x) / (2.0f * (float)M_PI));
+      *v = 0.5f + (asinf(delta.y) / (float)M_PI);
+      break;
+    }
+  }
+}
+
 /* render_kernel body for one pixel, kernel.hpp:44-59 */
 static void render_pixel(octx *cx, uint64_t x_id, uint64_t y_id, float fudge, int bounces, float *depth, vec *color, vec *normals, int64_t *hit_ids, uint64_t out_idx) {
   const ctr_scene_desc *s = cx->s;
@@ -305,6 +341,12 @@ static void render_pixel(octx *cx, uint64_t x_id, uint64_t y_id, float fudge, in
   depth[out_idx] = dist;
   normals[out_idx] = normal;
   if (hit_ids) hit_ids[out_idx] = did_hit ? (int64_t)hit_id : -1;
+  if (cx->uv) {
+    float u = 0.0f, v = 0.0f;
+    if (did_hit) uv_of_hit(&s->objects[hit_id], hit_point, &u, &v);
+    cx->uv[2 * out_idx + 0] = u;
+    cx->uv[2 * out_idx + 1] = v;
+  }
   color[out_idx] = ray_color(cx, &r, fudge, s->cam.ambient, bounces);
 }
 
@@ -320,11 +362,12 @@ typedef struct {
   int64_t *hit_ids;
   uint64_t *next;        /* shared atomic row counter */
   uint64_t casts, alg_bytes;
+  float *uv;
 } job;
 
 static void *worker(void *arg) {
   job *j = (job *)arg;
-  octx cx = {j->s, 0, 0, 0, -1};
+  octx cx = {j->s, 0, 0, 0, -1, j->uv};
   uint64_t w = j->s->cam.w;
   for (;;) {
     uint64_t k = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
@@ -347,8 +390,16 @@ static int row_selected(const ctr_rows *r, uint64_t y) {
  * counters (optional): [0]=ray_cast invocations, [1]=algorithmic bytes
  * (56·n_obj per cast + 48·n_tri per AABB-hit mesh + 28 per pixel).
  */
+int orc_render_uv(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
+                  float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2);
 int orc_render(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
                float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters) {
+  return orc_render_uv(s, fudge, bounces, rows_in, n_threads, depth, color3, normal3, hit_ids, counters, 0);
+}
+
+/* ... plus uv2 (optional): texture coordinates of the primary hit, 2 floats per pixel (0, 0 on a miss) */
+int orc_render_uv(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
+                  float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2) {
   ctr_rows rr = {0, s->cam.h, s->cam.h ? s->cam.h : 1, 0, 1};
   if (rows_in && rows_in->row_end > rows_in->row_begin) {
     rr = *rows_in;
@@ -365,7 +416,7 @@ int orc_render(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows
   job *jobs = (job *)calloc((size_t)n_threads, sizeof(job));
   pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
   for (int t = 0; t < n_threads; t++) {
-    job jj = {s, fudge, bounces, sel, n, depth, (vec *)color3, (vec *)normal3, hit_ids, &next, 0, 0};
+    job jj = {s, fudge, bounces, sel, n, depth, (vec *)color3, (vec *)normal3, hit_ids, &next, 0, 0, uv2};
     jobs[t] = jj;
   }
   if (n_threads == 1) worker(&jobs[0]);
@@ -382,7 +433,7 @@ int orc_render(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows
 
 /* debugging aid: print every ray_cast of one pixel (origin, direction, winner) */
 void orc_trace_pixel(const ctr_scene_desc *s, uint64_t x, uint64_t y, float fudge, int bounces) {
-  octx cx = {s, 0, 0, 1, -1};
+  octx cx = {s, 0, 0, 1, -1, 0};
   float depth;
   vec color, normal;
   render_pixel(&cx, x, y, fudge, bounces, &depth, &color, &normal, 0, 0);

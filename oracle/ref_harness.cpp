@@ -161,8 +161,16 @@ extern "C" {
 
 // Same contract as orc_render (oracle/ctr_oracle.c).  counters[0] = ray_cast
 // invocations; counters[1] is left 0 (only the restatement counts bytes).
+// ... plus uv2 (optional): ray_cast's tex_coords of the primary cast (kernel.hpp:51-52), 2 floats per pixel
+int ref_render_uv(const ctr_scene_desc *d, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
+                  float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2);
 int ref_render(const ctr_scene_desc *d, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
                float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters) {
+  return ref_render_uv(d, fudge, bounces, rows_in, n_threads, depth, color3, normal3, hit_ids, counters, nullptr);
+}
+
+int ref_render_uv(const ctr_scene_desc *d, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
+                  float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2) {
   built_scene b;
   build(d, b, counters != nullptr);
   const scene_t *scene = &b.scene;
@@ -201,6 +209,7 @@ int ref_render(const ctr_scene_desc *d, float fudge, int bounces, const ctr_rows
         depth[px] = dist;
         normal3[3 * px + 0] = normal.x; normal3[3 * px + 1] = normal.y; normal3[3 * px + 2] = normal.z;
         if (hit_ids) hit_ids[px] = (did_hit && hit_id < n_real_objects) ? (int64_t)hit_id : -1;
+        if (uv2) { uv2[2 * px + 0] = tc.u; uv2[2 * px + 1] = tc.v; }
         vector c = color_dispatch(scene, &r, fudge, bounces);
         color3[3 * px + 0] = c.x; color3[3 * px + 1] = c.y; color3[3 * px + 2] = c.z;
       }

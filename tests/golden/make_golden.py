@@ -48,7 +48,20 @@ def sums(r):
     )
 
 
+UV = [("triangle", 20, 20), ("sphere_plane", 96, 54), ("bunny", 96, 54)]
+
+
 def main():
+    # texture coordinates of the primary hit (ray_cast's tex_coords), straight from the reference build
+    for name, w, h in UV:
+        s = ca.HostScene.load(f"scene/{name}.json")
+        s.set_size(w, h)
+        r = oracle.ref_render(s, bounces=0, threads=THREADS, uv=True)
+        path = os.path.join(OUT, f"uv_{name}_{w}x{h}.npz")
+        np.savez_compressed(path, uv=r["uv"], hit_id=r["hit_id"].astype(np.int32), depth=r["depth"])
+        print("wrote", path)
+    if "--uv-only" in sys.argv:
+        return
     only_small = "--small" in sys.argv
     for name, w, h, b in SMALL:
         s = ca.HostScene.load(f"scene/{name}.json")

@@ -719,3 +719,51 @@ def test_delivery_self_check(ca, monkeypatch):
         for _ in range(2):
             r = ds.render(bounces=3, pinned=True)     # raises if the self-check fails
         assert r["ray_count"] > 0
+
+
+def _uv_close(got, want, tol=1e-4):
+    """uv within the parity bar; NaN where the reference has NaN (plane normal without x and y, default_schema.hpp:170)"""
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), f"{int((nan_g != nan_w).sum())} uv values are NaN on one side only"
+    d = np.abs(np.where(nan_w, 0, got) - np.where(nan_w, 0, want))
+    lim = tol * np.maximum(1.0, np.abs(np.where(nan_w, 0, want)))
+    assert (d <= lim).all(), f"uv differs by up to {float(d.max()):.3e}"
+    return float(d.max())
+
+
+@pytest.mark.parametrize("name,w,h", [("triangle", 20, 20), ("sphere_plane", 96, 54), ("bunny", 96, 54)])
+def test_texture_coordinates_against_reference_fixture(ca, name, w, h):
+    """ctr_render_uv: the fourth output (ray_cast's tex_coords of the primary hit) against the reference build's buffers
+    (tests/golden/uv_*.npz): triangle, plane, sphere and mesh formulas.  Triangle / plane / mesh coordinates are plain
+    float arithmetic on the hit point and come out bit-identical; the sphere's go through atan2f / asinf, whose device
+    versions differ from glibc's in the last bits (bar: 1e-4, the north star's per-channel tolerance).  The other three
+    buffers are those of ctr_render, bit for bit."""
+    g = np.load(os.path.join(GOLD, f"uv_{name}_{w}x{h}.npz"))
+    s = load_scene(ca, name, w, h)
+    ds = ca.DeviceScene(s)
+    r = ds.render_uv(bounces=0)
+    worst = _uv_close(r["uv"], g["uv"])
+    hit = g["hit_id"]
+    kinds = {0: "triangle", 1: "mesh", 2: "plane", 3: "sphere"}
+    types = [int(o.type) for o in s.desc.contents.objects[:s.desc.contents.n_objects]]
+    exact = np.ones(hit.shape, bool)
+    for i, t in enumerate(types):
+        if kinds[t] == "sphere":
+            exact &= hit != i
+    a, b = r["uv"][exact], g["uv"][exact]
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32)), \
+        "uv of non-sphere hits must be bit-identical"
+    plain = ds.render(bounces=0)
+    for k in ("depth", "normal", "color"):
+        assert same_bits(r[k], plain[k]), k
+    print(f"uv {name}: max |diff| {worst:.2e} ({int((~exact).sum())} sphere pixels through atan2f/asinf)")
+
+
+def test_texture_coordinates_random_scenes_vs_oracle(ca):
+    """the same against the oracle on seeded scenes that mix every primitive (stand-alone triangles included)"""
+    for seed in range(6):
+        s = ca.HostScene.parse(_random_scene(seed, w=96, h=64))
+        o = oracle.oracle_render(s, bounces=1, threads=os.cpu_count() or 4, uv=True)
+        r = ca.DeviceScene(s).render_uv(bounces=1)
+        _uv_close(r["uv"], o["uv"])
+        assert same_bits(r["depth"], o["depth"]) and same_bits(r["normal"], o["normal"])

@@ -194,3 +194,24 @@ def test_cuda_minmax_semantics_gap(ca):
         for k in ("depth", "normal", "color"):
             assert same_bits(a[k], c[k]), (name, k)
         assert a["ray_count"] == c["ray_count"]
+
+
+UV_FIXTURES = [("triangle", 20, 20), ("sphere_plane", 96, 54), ("bunny", 96, 54)]
+
+
+@pytest.mark.parametrize("name,w,h", UV_FIXTURES)
+def test_oracle_texture_coordinates_match_reference_fixture(ca, name, w, h):
+    """ray_cast's tex_coords of the primary hit (triangle::uv_for, plane::uv_for, the sphere's atan2 / asin, a mesh's
+    (hit.x, hit.y): default_schema.hpp:37-46,138-139,169-178,246-249): the C restatement against buffers the reference
+    build wrote (tests/golden/make_golden.py --uv-only), bit for bit, NaNs included (a plane whose normal has no x and y
+    normalises a zero vector, :170)."""
+    g = np.load(os.path.join(GOLD, f"uv_{name}_{w}x{h}.npz"))
+    s = ca.HostScene.load(f"scene/{name}.json")
+    s.set_size(w, h)
+    r = oracle.oracle_render(s, bounces=0, threads=4, uv=True)
+    assert np.array_equal(r["uv"].view(np.uint32), g["uv"].view(np.uint32))
+    assert np.array_equal(r["hit_id"], g["hit_id"])
+    ref = oracle.ref_lib()
+    if ref is not None and hasattr(ref, "ref_render_uv"):
+        live = oracle.ref_render(s, bounces=0, threads=4, uv=True)
+        assert np.array_equal(live["uv"].view(np.uint32), g["uv"].view(np.uint32))
