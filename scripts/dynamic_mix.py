@@ -118,6 +118,12 @@ def main():
             "modelled_over_measured_salu_with_branches": round((tot["salu"] + tot["nop"] + tot["branch"]) / pmc["salu_insts_per_launch"], 4),
             "SQ_INSTS_SMEM": pmc["smem_insts_per_launch"], "modelled_over_measured_smem": round(tot["smem"] / pmc["smem_insts_per_launch"], 4),
         }
+        if pmc.get("valu_trans_f32_insts"):
+            res["pmc_check"]["SQ_INSTS_VALU_TRANS_F32"] = pmc["valu_trans_f32_insts"]
+            res["pmc_check"]["modelled_over_measured_transcendental"] = round(tot["Q"] / pmc["valu_trans_f32_insts"], 4)
+        # what the miscount of the VALU total can do to the mean: were all of it plain (F) or all of it half-rate (H) instructions
+        over = valu - pmc["valu_insts_per_launch"]
+        res["mean_issue_cycles_bracket"] = sorted(round((cyc - over * c) / pmc["valu_insts_per_launch"], 4) for c in (F, H))
         if pmc.get("active_inst_valu_quadcycles"):
             qm = pmc["active_inst_valu_quadcycles"] - pmc["valu_insts_per_launch"]
             res["pmc_check"]["Q_measured(ACTIVE_INST_VALU-INSTS_VALU)"] = qm

@@ -9,6 +9,7 @@ scene's first launch, in image order — is left out):
                                MI355X_MICROARCH.md §HBM), each from its own pass
 usage: pmc_counters.py <dir-prefix> <kernel-substring> <workload> <out.json>"""
 import csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 prefix, kern, workload, out = sys.argv[1:5]
 
 
@@ -49,12 +50,13 @@ res = {
     "wave_quadcycles_per_launch": mean(sq1, "SQ_WAVE_CYCLES"), "wait_any_quadcycles": mean(sq1, "SQ_WAIT_ANY"),
     "wait_inst_any_quadcycles": mean(sq1, "SQ_WAIT_INST_ANY"),
     "active_inst_valu_quadcycles": mean(sq2, "SQ_ACTIVE_INST_VALU"), "active_inst_any_quadcycles": mean(sq2, "SQ_ACTIVE_INST_ANY"),
-    "thread_cycles_valu": mean(sq2, "SQ_THREAD_CYCLES_VALU"),
+    "thread_cycles_valu": mean(sq2, "SQ_THREAD_CYCLES_VALU"), "valu_trans_f32_insts": mean(sq2, "SQ_INSTS_VALU_TRANS_F32"),
     "sqc_dcache_req": mean(sqc, "SQC_DCACHE_REQ"), "sqc_dcache_hits": mean(sqc, "SQC_DCACHE_HITS"),
     "sqc_dcache_misses": mean(sqc, "SQC_DCACHE_MISSES"), "sqc_dcache_misses_duplicate": mean(sqc, "SQC_DCACHE_MISSES_DUPLICATE"),
     "cycles_per_launch": cyc, "kernel_ns_in_pmc_pass": t_ns, "effective_clock_ghz": cyc / t_ns,
     "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk, "fetch_correction": 2.0,
     "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
+    "kernel_source_sha256": __import__("bench").kernel_source_hash(),
     "source": "scripts/gpu_pmc.sh -> scripts/pmc_counters.py",
 }
 json.dump(res, open(out, "w"), indent=1)
