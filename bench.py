@@ -491,7 +491,9 @@ def main():
         value = total_rays / dt_max / 1e6
         workload = f"{os.path.basename(args.scene)}@{w}x{h}b{args.bounces}"
         # ---- roofline of the dominant (only) kernel, per launch: VALU issue ----
-        roof = roofline_from_profiles(workload, kern_avg if (world == 1 and frames == 1) else 0.0, args.counters_json)
+        # (the committed counters describe ONE launch of ONE whole frame: no fraction is claimed for a step of several frames
+        #  or a part of a frame)
+        roof = roofline_from_profiles(workload if (world == 1 and frames == 1 and not sim) else "", kern_avg, args.counters_json)
         config = {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
                               f"{frames} frame(s)/step row-tiled over {world} GPU(s), "
                               + ("frame f gathered to rank f mod N" if tiler.rotate_roots else "gather to rank 0"),

@@ -43,8 +43,10 @@
 //  * arguments that only the continuation or the start of a cast needs are re-read from the kernarg
 //    segment instead of living in SGPRs across the inner loops (no spill reloads by v_readlane); the
 //    build avoids SLP vectorisation (compiler-made v_pk_* cost more in shuffles than they save).
-//  * two builds of the default variant: 87 VGPRs = 5 waves per SIMD, and (KV_OCC6) 80 VGPRs with ten
-//    spilled to scratch = 6 waves, picked for scenes with >= 1000 mesh triangles.
+//  * two builds of the default variant: 85 VGPRs = 5 waves per SIMD, and (KV_OCC6) 80 VGPRs = 6 waves, picked for scenes
+//    with >= 1000 mesh triangles: five cold dwords of shading state live in one 1280-byte LDS granule behind the wave's
+//    stack instead (PARK), mode and stack depth share a register, lane-derived addresses are recomputed from v_mbcnt.
+//    No instantiation uses scratch memory.
 //
 // Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE correctly rounded on gfx950,
 // so every geometric quantity (depth, hit, normal, which object is hit) is bit-identical to the
@@ -1957,10 +1959,10 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
   if (L.variant & KV_STATS)
     return (L.variant & KV_ANYHIT) ? launch<KV_BVH | KV_PREFILTER | KV_ANYHIT | KV_FASTPOW | KV_STATS>(L, s)
                                    : launch<KV_BVH | KV_PREFILTER | KV_FASTPOW | KV_STATS>(L, s);
-  // KV_OCC6: the same kernel compiled for 6 waves per SIMD (80 VGPRs, ~10 of them spilled to scratch once per
-  // trip) instead of 5 (87, none): worth it where the mesh data exceed the scalar cache many times over and a
-  // wave mostly waits for L2 (ctr_api.cpp picks it by triangle count); only the shipped default variant has it
-  // (and only when 24 waves' recursion stacks fit the CU's 160 KB of LDS: bounces <= 6 without cold frames)
+  // KV_OCC6: the same kernel compiled for 6 waves per SIMD (80 VGPRs; five cold dwords parked in LDS, see PARK) instead
+  // of 5 (85): worth it where the mesh data exceed the scalar cache many times over and a wave mostly waits for L2
+  // (ctr_api.cpp picks it by triangle count); only the shipped default variant has it (and only when 24 waves' recursion
+  // stacks plus the parking granule fit the CU's 160 KB of LDS: bounces <= 5 without cold frames, occ6_fits)
   const size_t stack_bytes = (size_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1) * (L.need_cold_frames ? 10u : 4u) * 64 * sizeof(float);
   if ((L.variant & KV_OCC6) && occ6_fits(stack_bytes) &&
       (L.variant & (KV_PREFILTER | KV_ANYHIT | KV_BVH | KV_FASTPOW)) == (KV_PREFILTER | KV_ANYHIT | KV_BVH | KV_FASTPOW))

@@ -273,3 +273,25 @@ def test_bench_c4_strong_two_ranks_on_one_gpu(ca):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["frames_per_step"] == 1
     assert "bunny_grid4x4.json@512x512" in line["config"]["workload"] and "gather to rank 0" in line["config"]["workload"]
+
+
+def test_bench_default_line_two_ranks_on_one_gpu(ca):
+    """The driver's multi-GPU command as it stands (weak scaling on bunny.json, rotating roots) rehearsed with two ranks on
+    the one GPU (gloo instead of RCCL): it must still end in ONE JSON line, now carrying BASELINE config 5 measured in the
+    same run (config.c4_strong: the 4x4 grid @4096x4096, one frame per step row-tiled over both ranks, gathered to rank 0)."""
+    import json
+    import socket
+    import sys
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, CUTRACE_BENCH_SHARE_GPU="1", CUTRACE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--check"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frames_per_step"] == 2
+    c4 = line["config"]["c4_strong"]
+    assert c4["n_gpus"] == 2 and c4["rays_per_frame"] == 520093696 and c4["frame_ms"] > 0
+    assert line["roofline"]["frac"] is None          # a per-launch fraction is claimed for the one-GPU workload only

@@ -561,7 +561,7 @@ def test_exact_sqrt_and_reciprocal_shortcut_is_exhaustively_correct(ca):
 
 
 def test_six_wave_build_and_pinned_frames_change_nothing(ca):
-    """The build compiled for 6 waves per SIMD (picked for >= 1000 mesh triangles; ten VGPRs spilled to scratch) against
+    """The build compiled for 6 waves per SIMD (picked for >= 1000 mesh triangles; five cold dwords parked in LDS) against
     the 5-wave build, and delivery into a page-locked frame block (one DMA) against pageable buffers: same bytes."""
     s = load_scene(ca, "bunny")            # 1000 triangles: the 6-wave build by default
     ds = ca.DeviceScene(s)
