@@ -312,6 +312,18 @@ def roofline_from_profiles(workload, kern_avg_ms, counters_json):
         "wait_any_share_of_wave_cycles": (cnt["wait_any_quadcycles"] / cnt["wave_quadcycles_per_launch"]) if cnt.get("wave_quadcycles_per_launch") else None,
         "source": f"profiles/r03/counters_{tag}.json (rocprofv3 --pmc passes of bench.py on this workload), "
                   f"profiles/r03/valu_mix_dynamic_{tag}.json (execution-weighted mix, scripts/dynamic_mix.py), profiles/r02/valu_issue.txt"})
+    ij = os.path.join(PROFILE_DIR, "issue_mix_measured.json")
+    if os.path.exists(ij):
+        # the additive pricing (sum of per-kind costs) against a MEASURED stream of the kernel's mix: mixing plain and
+        # half-rate instructions costs a little less than the sum (3.12 vs 3.25 cycles per VALU at 6 waves per SIMD), and
+        # the scalar instructions between them are not free (3.49 with the kernel's 0.65 SALU per VALU)
+        im = json.load(open(ij))
+        scale = cost / im["additive_model_cycles_per_valu"]  # the kernel's mix differs slightly from the stream's
+        spent = 1024.0 * cycles / cnt["valu_insts_per_launch"]
+        roof["simd_cycles_spent_per_valu"] = spent
+        roof["frac_valu_issue_measured_stream"] = im["measured_valu_only"] * scale / spent
+        roof["frac_issue_incl_scalar_measured_stream"] = im["measured_with_salu"] * scale / spent
+        roof["issue_mix_measured"] = {k: im[k] for k in ("waves_per_simd", "measured_valu_only", "measured_with_salu", "additive_model_cycles_per_valu")}
     if kern_avg_ms and kern_avg_ms > 0:
         clock = cycles / (kern_avg_ms * 1e-3) / 1e9
         roof.update({"achieved": cnt["valu_insts_per_launch"] * cost / (kern_avg_ms * 1e-3) / 1e9, "peak": 1024.0 * clock,

@@ -60,7 +60,7 @@ struct ModeInfo {
 enum {
   M_FMA_V = 0, M_FMA_S, M_FMAC_V, M_FMAC_S, M_MUL_S, M_ADD_V, M_MAX3_V, M_FMA_INL, M_PK_V, M_PK_S, M_PKMUL_S,
   M_CMP_VCC, M_CMP_S64, M_CMP_SOP, M_MOV_S, M_READLANE, M_CNDMASK_S, M_RCP, M_DEP, M_SALU, M_SALU64, M_FMA_SALU,
-  M_MIX, M_COUNT
+  M_MIX, M_KMIX, M_KMIX_NOSALU, M_COUNT
 };
 static const ModeInfo modes[M_COUNT] = {
     {"fma_v       v_fma_f32 v,v,v,v            (VGPR operands only)", 8, 8},
@@ -86,6 +86,12 @@ static const ModeInfo modes[M_COUNT] = {
     {"salu64      s_and_b64 / s_or_b64 (independent)", 0, 8},
     {"fma_salu    v_fma_f32 (VGPR only) alternating with s_add_u32", 4, 8},
     {"mix         6 fma_s + 2 pk_s + 2 cmp_s64 + 3 SALU (render-like, 13 instructions)", 10, 13},
+    // round 3: a stream with the render kernel's EXECUTED mix (profiles/r03/valu_mix_dynamic_bunny.json: F 0.525, H 0.460,
+    // Q 0.015 of the VALU instructions; 0.64 SALU per VALU): 40 VALU = 20 plain + 19 half-rate (9 with an SGPR operand, 4
+    // packed with an SGPR pair, 4 compares into SGPR pairs, 2 max3) + 1 transcendental, and 26 SALU between them.  The
+    // additive model prices it (20 x 2.2 + 19 x 4.1 + 8.1) / 40 = 3.25 cycles per VALU; what does the SIMD take?
+    {"kmix        the render kernel's executed mix: 20 F + 19 H + 1 Q VALU + 26 SALU", 40, 66},
+    {"kmix_nosalu the same 40 VALU without the scalar instructions", 40, 40},
 };
 
 template <int MODE>
@@ -171,6 +177,28 @@ __global__ void bench(Rec *out, int iters, float seed) {
               "v_fma_f32 %4, %15, %4, %14\n v_fma_f32 %5, %15, %5, %14\n v_cmp_lt_f32_e64 s[42:43], %0, %1\n"
               "v_cmp_lt_f32_e64 s[44:45], %2, %3\n s_or_b64 s[46:47], s[42:43], s[44:45]\n"));
     }
+#define KM_V1 "v_fma_f32 %0, %0, %13, %14\n v_fma_f32 %1, %15, %1, %14\n v_fma_f32 %2, %2, %13, %14\n v_pk_fma_f32 %8, %16, %8, %17\n v_fma_f32 %3, %3, %13, %14\n"
+#define KM_V2 "v_fma_f32 %4, %15, %4, %14\n v_fma_f32 %5, %5, %13, %14\n v_cmp_lt_f32_e64 s[42:43], %0, %1\n v_fma_f32 %6, %6, %13, %14\n v_fma_f32 %7, %15, %7, %14\n"
+#define KM_V3 "v_fma_f32 %0, %0, %13, %14\n v_max3_f32 %1, %1, %13, %14\n v_fma_f32 %2, %2, %13, %14\n v_pk_fma_f32 %9, %16, %9, %17\n v_fma_f32 %3, %3, %13, %14\n"
+#define KM_V4 "v_fma_f32 %4, %15, %4, %14\n v_fma_f32 %5, %5, %13, %14\n v_cmp_lt_f32_e64 s[44:45], %2, %3\n v_fma_f32 %6, %6, %13, %14\n v_fma_f32 %7, %15, %7, %14\n"
+#define KM_V5 "v_fma_f32 %0, %0, %13, %14\n v_fma_f32 %1, %15, %1, %14\n v_fma_f32 %2, %2, %13, %14\n v_pk_fma_f32 %10, %16, %10, %17\n v_fma_f32 %3, %3, %13, %14\n"
+#define KM_V6 "v_fma_f32 %4, %15, %4, %14\n v_fma_f32 %5, %5, %13, %14\n v_cmp_lt_f32_e64 s[46:47], %4, %5\n v_fma_f32 %6, %6, %13, %14\n v_rcp_f32_e32 %7, %7\n"
+#define KM_V7 "v_fma_f32 %0, %0, %13, %14\n v_max3_f32 %1, %1, %13, %14\n v_fma_f32 %2, %2, %13, %14\n v_pk_fma_f32 %11, %16, %11, %17\n v_fma_f32 %3, %3, %13, %14\n"
+#define KM_V8 "v_fma_f32 %4, %15, %4, %14\n v_fma_f32 %5, %5, %13, %14\n v_cmp_lt_f32_e64 s[48:49], %6, %7\n v_fma_f32 %6, %6, %13, %14\n v_fma_f32 %7, %15, %7, %14\n"
+#define KM_S3a "s_add_u32 %12, %12, 1\n s_and_b64 s[50:51], s[42:43], s[44:45]\n s_and_b32 s40, %12, 7\n"
+#define KM_S3b "s_or_b64 s[52:53], s[46:47], s[48:49]\n s_add_u32 s41, s40, 3\n s_andn2_b64 s[54:55], s[50:51], s[52:53]\n"
+#define KM_S4 "s_lshl_b32 s40, s41, 2\n s_cmp_lg_u64 s[54:55], 0\n s_cselect_b32 s41, s40, 5\n s_add_u32 %12, %12, s41\n"
+    if (MODE == M_KMIX) {  // 8 groups of 5 VALU, 26 SALU spread between them
+      BODY(KM_V1 KM_S3a KM_V2 KM_S3b KM_V3 KM_S4 KM_V4 KM_S3a KM_V5 KM_S3b KM_V6 KM_S4 KM_V7 KM_S3a KM_V8 KM_S3b);
+      BODY(KM_V1 KM_S3a KM_V2 KM_S3b KM_V3 KM_S4 KM_V4 KM_S3a KM_V5 KM_S3b KM_V6 KM_S4 KM_V7 KM_S3a KM_V8 KM_S3b);
+      BODY(KM_V1 KM_S3a KM_V2 KM_S3b KM_V3 KM_S4 KM_V4 KM_S3a KM_V5 KM_S3b KM_V6 KM_S4 KM_V7 KM_S3a KM_V8 KM_S3b);
+      BODY(KM_V1 KM_S3a KM_V2 KM_S3b KM_V3 KM_S4 KM_V4 KM_S3a KM_V5 KM_S3b KM_V6 KM_S4 KM_V7 KM_S3a KM_V8 KM_S3b);
+      BODY(KM_V1 KM_S3a KM_V2 KM_S3b KM_V3 KM_S4 KM_V4 KM_S3a KM_V5 KM_S3b KM_V6 KM_S4 KM_V7 KM_S3a KM_V8 KM_S3b);
+      BODY(KM_V1 KM_S3a KM_V2 KM_S3b KM_V3 KM_S4 KM_V4 KM_S3a KM_V5 KM_S3b KM_V6 KM_S4 KM_V7 KM_S3a KM_V8 KM_S3b);
+      BODY(KM_V1 KM_S3a KM_V2 KM_S3b KM_V3 KM_S4 KM_V4 KM_S3a KM_V5 KM_S3b KM_V6 KM_S4 KM_V7 KM_S3a KM_V8 KM_S3b);
+      BODY(KM_V1 KM_S3a KM_V2 KM_S3b KM_V3 KM_S4 KM_V4 KM_S3a KM_V5 KM_S3b KM_V6 KM_S4 KM_V7 KM_S3a KM_V8 KM_S3b);
+    }
+    if (MODE == M_KMIX_NOSALU) { R8(BODY(KM_V1 KM_V2 KM_V3 KM_V4 KM_V5 KM_V6 KM_V7 KM_V8)); }
   }
   const uint64_t t1 = __builtin_amdgcn_s_memtime();
   const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
@@ -329,6 +357,8 @@ int main(int argc, char **argv) {
   run_mode<M_SALU64>(d_out, n_cu, filter);
   run_mode<M_FMA_SALU>(d_out, n_cu, filter);
   run_mode<M_MIX>(d_out, n_cu, filter);
+  run_mode<M_KMIX>(d_out, n_cu, filter);
+  run_mode<M_KMIX_NOSALU>(d_out, n_cu, filter);
   run_chase(d_out, n_cu, filter);
   HIP_OK(hipFree(d_out));
   return 0;
