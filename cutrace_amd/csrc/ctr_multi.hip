@@ -201,6 +201,7 @@ int ensure_buffers(ctr_multi *m, uint64_t block_rows) {
   if (cap == 0) cap = 1;
   if (cap > m->cap_px) {
     if (m->inflight) return mfail(CTR_E_INVALID, "ctr_multi: the frame grew while frames are in flight (ctr_multi_wait first)");
+    m->cap_px = 0;  // (an allocation that fails below leaves null buffers: the next call must come back here whatever its size)
     for (uint32_t p = 0; p < n; p++) {
       Part &P = m->parts[p];
       for (int q = 0; q < SLOTS; q++) {
@@ -221,6 +222,7 @@ int ensure_buffers(ctr_multi *m, uint64_t block_rows) {
   if (m->w * m->h > m->frame_px && n > 1) {
     if (m->inflight) return mfail(CTR_E_INVALID, "ctr_multi: the frame grew while frames are in flight (ctr_multi_wait first)");
     MHIP(hipSetDevice(m->parts[0].device));
+    m->frame_px = 0;
     for (int q = 0; q < SLOTS; q++) {
       if (m->frame[q]) (void)hipFree(m->frame[q]);
       m->frame[q] = nullptr;
