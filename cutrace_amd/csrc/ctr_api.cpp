@@ -111,7 +111,7 @@ struct ctr_scene {
   uint32_t n_mesh = 0, tlas_root = BVH_LEAF_FLAG, tlas_begin = 0;
   float tl_mn[3] = {0, 0, 0}, tl_mx[3] = {0, 0, 0};
   DPlanePair *d_planes = nullptr;
-  uint32_t n_oloop = 0, n_planes = 0;
+  uint32_t n_oloop = 0, n_plane_recs = 0, n_axis_recs = 0;
   DTri *d_tris = nullptr;
   DNode *d_nodes = nullptr;
   DNode4 *d_nodes4 = nullptr;
@@ -242,7 +242,8 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   for (int q = 0; q < 3; q++) { L.tl_mn[q] = s->tl_mn[q]; L.tl_mx[q] = s->tl_mx[q]; }
   L.planes = s->d_planes;
   L.n_oloop = s->n_oloop;
-  L.n_planes = s->n_planes;
+  L.n_plane_recs = s->n_plane_recs;
+  L.n_axis_recs = s->n_axis_recs;
   L.tris = s->d_tris;
   L.nodes = s->d_nodes;
   L.nodes4 = s->d_nodes4;
@@ -662,25 +663,66 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     }
   }
   std::vector<DObj> oloop, meshes_in, meshes;
+  uint32_t n_axis_recs = 0;
   std::vector<DPlanePair> planes;
-  uint32_t n_planes = 0;
+  std::vector<const DObj *> axis_planes[3], general_planes;
   for (const DObj &O : objs) {
     if (O.type == CTR_OBJ_PLANE) {
-      if (n_planes % 2 == 0) {
-        DPlanePair pr;  // second slot starts as a copy of the first and is marked as padding
-        for (int a = 0; a < 3; a++) { pr.p[a][0] = pr.p[a][1] = O.f[a]; pr.n[a][0] = pr.n[a][1] = O.f[3 + a]; }
-        pr.index[0] = O.index;
-        pr.index[1] = CTR_PLANE_PAD;
-        pr.pad[0] = pr.pad[1] = 0;
-        planes.push_back(pr);
-      } else {
-        DPlanePair &pr = planes.back();
-        for (int a = 0; a < 3; a++) { pr.p[a][1] = O.f[a]; pr.n[a][1] = O.f[3 + a]; }
-        pr.index[1] = O.index;
+      // axis-aligned: exactly one normal component is not zero (+0 and -0 both count as zero), everything finite
+      int nz = 0, axis = -1;
+      bool finite = true;
+      for (int a = 0; a < 3; a++) {
+        if (!std::isfinite(O.f[a]) || !std::isfinite(O.f[3 + a])) finite = false;
+        if (O.f[3 + a] != 0.0f) { nz++; axis = a; }
       }
-      n_planes++;
+      if (finite && nz == 1) axis_planes[axis].push_back(&O);
+      else general_planes.push_back(&O);
     } else if (O.type == CTR_OBJ_MESH) { if (O.tri_count) meshes_in.push_back(O); }  // an empty mesh is never hit
     else oloop.push_back(O);
+  }
+  {
+    auto empty_pair = [] {
+      DPlanePair pr;
+      for (int a = 0; a < 3; a++) { pr.p[a][0] = pr.p[a][1] = 0.0f; pr.n[a][0] = pr.n[a][1] = 1.0f; }
+      pr.index[0] = pr.index[1] = CTR_PLANE_PAD;
+      pr.pad[0] = pr.pad[1] = 0;
+      return pr;
+    };
+    auto put = [](DPlanePair &pr, int slot, const DObj &O) {
+      for (int a = 0; a < 3; a++) { pr.p[a][slot] = O.f[a]; pr.n[a][slot] = O.f[3 + a]; }
+      pr.index[slot] = O.index;
+    };
+    // fewer than three axis-aligned planes (a lone floor): one general record is less to fetch than a triple
+    if (axis_planes[0].size() + axis_planes[1].size() + axis_planes[2].size() < 3) {
+      general_planes.clear();
+      for (int a = 0; a < 3; a++) axis_planes[a].clear();
+      for (const DObj &O : objs)
+        if (O.type == CTR_OBJ_PLANE) general_planes.push_back(&O);
+    }
+    // axis triples: as many as the busiest axis needs (a box room: one)
+    size_t triples = 0;
+    for (int a = 0; a < 3; a++) triples = std::max(triples, (axis_planes[a].size() + 1) / 2);
+    for (size_t t = 0; t < triples; t++)
+      for (int a = 0; a < 3; a++) {
+        DPlanePair pr = empty_pair();
+        for (int slot = 0; slot < 2; slot++)
+          if (2 * t + slot < axis_planes[a].size()) put(pr, slot, *axis_planes[a][2 * t + slot]);
+        // an empty slot copies its neighbour (same numbers, never tested)
+        if (pr.index[0] != CTR_PLANE_PAD && pr.index[1] == CTR_PLANE_PAD)
+          for (int q = 0; q < 3; q++) { pr.p[q][1] = pr.p[q][0]; pr.n[q][1] = pr.n[q][0]; }
+        planes.push_back(pr);
+      }
+    n_axis_recs = (uint32_t)planes.size();
+    for (size_t k = 0; k < general_planes.size(); k++) {
+      if (k % 2 == 0) {
+        DPlanePair pr = empty_pair();
+        put(pr, 0, *general_planes[k]);
+        for (int q = 0; q < 3; q++) { pr.p[q][1] = pr.p[q][0]; pr.n[q][1] = pr.n[q][0]; }
+        planes.push_back(pr);
+      } else {
+        put(planes.back(), 1, *general_planes[k]);
+      }
+    }
   }
   // top-level BVH over the mesh boxes, one mesh per leaf (same node layout as the per-mesh trees)
   uint32_t tlas_root = BVH_LEAF_FLAG, tlas_begin = (uint32_t)nodes.size();
@@ -738,7 +780,9 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
 
   auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
     // never hand the kernel a null base pointer: allocate at least one element's worth
-    hipError_t er = hipMalloc(dst, bytes ? bytes : 64);
+    // (and 256 bytes beyond the end: the leaf loop requests the three cache lines after a leaf's first triangle ahead
+    //  of their use, whether the leaf has that many triangles or not — render_kernel.hip, "touch")
+    hipError_t er = hipMalloc(dst, (bytes ? bytes : 64) + 256);
     if (er != hipSuccess) return er;
     if (bytes) er = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     return er;
@@ -749,7 +793,8 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->tlas_root = tlas_root;
   s->tlas_begin = tlas_begin;
   for (int q = 0; q < 3; q++) { s->tl_mn[q] = tl_mn[q]; s->tl_mx[q] = tl_mx[q]; }
-  s->n_planes = n_planes;
+  s->n_plane_recs = (uint32_t)planes.size();
+  s->n_axis_recs = n_axis_recs;
   if ((er = upload((void **)&s->d_objs, objs.data(), objs.size() * sizeof(DObj))) != hipSuccess ||
       (er = upload((void **)&s->d_oloop, oloop.data(), oloop.size() * sizeof(DObj))) != hipSuccess ||
       (er = upload((void **)&s->d_meshes, meshes.data(), meshes.size() * sizeof(DObj))) != hipSuccess ||

@@ -60,6 +60,7 @@
 // are never produced: the only material type ignores them (default_schema.hpp:326-340).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -183,6 +184,21 @@ __device__ __forceinline__ float slab_hi4(float ax, float bx, float ay, float by
 __device__ __forceinline__ float2_ ldpair(const CADDR float (&p)[2]) { return *(const CADDR float2_ *)p; }
 __device__ __forceinline__ float2_ ldpair2(const CADDR float *p) { return *(const CADDR float2_ *)p; }
 
+// one triangle record as register values (SGPRs: the record is wave-uniform)
+struct TriR {
+  float2_ ab0, ab1, ab2, pxy;
+  float pz;
+  uint32_t orig;
+  float nx, ny, nz, ke, ke2;
+};
+__device__ __forceinline__ TriR load_tri(const CADDR DTri &T) {
+  TriR r;
+  r.ab0 = ldpair(T.ab[0]); r.ab1 = ldpair(T.ab[1]); r.ab2 = ldpair(T.ab[2]);
+  r.pxy = ldpair2(&T.px); r.pz = T.pz; r.orig = T.orig;
+  r.nx = T.nx; r.ny = T.ny; r.nz = T.nz; r.ke = T.ke; r.ke2 = T.ke2;
+  return r;
+}
+
 // ---- inc/vector.hpp, same operation order -------------------------------------
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -254,28 +270,31 @@ __device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a
 enum { F_R = 0, F_G, F_B, F_MAT, F_PX, F_PY, F_PZ, F_DX, F_DY, F_DZ };  // F_MAT: material index | stage << 30
 
 struct KArgs {
-  const CADDR DObj *objs;      // every object in scene order (hit records)
-  const CADDR DObj *oloop;     // spheres and stand-alone triangles (sequential loop)
-  const CADDR DObj *meshes;    // meshes with >= 1 triangle, in top-level-BVH leaf order
-  uint32_t n_mesh, tlas_root, tlas_begin;
-  float tl_mn[3], tl_mx[3];    // box of all meshes (margin of the top-level walk)
+  // hot block, the first 32 bytes: what every cast needs before it reaches a mesh — fetched with ONE s_load_dwordx8 at
+  // the head of the trip instead of five dependent scalar loads spread over it (each a round trip the wave waits for)
   const CADDR DPlanePair *planes;
-  uint32_t n_oloop, n_planes;
-  const CADDR DTri *tris;
-  const CADDR DNode *nodes;    // top-level tree over the meshes (two-wide nodes)
-  const CADDR DNode4 *nodes4;  // per-mesh trees (four-wide nodes)
+  uint32_t n_plane_recs, n_axis_recs, n_oloop, n_mesh, tlas_root, has_mesh;
+  // cold block, the next 48 bytes: what the continuation needs, fetched together at its start
+  const CADDR DObj *objs;      // every object in scene order (hit records)
   const CADDR float *gnorm;
   const CADDR DLight *lights;
   const CADDR DMat *mats;
-  uint32_t n_obj, n_light;
+  uint32_t n_light;
+  int bounces;
+  uint32_t n_obj, pad0;
+  const CADDR DObj *oloop;     // spheres and stand-alone triangles (sequential loop)
+  const CADDR DObj *meshes;    // meshes with >= 1 triangle, in top-level-BVH leaf order
+  uint32_t tlas_begin;
+  float tl_mn[3], tl_mx[3];    // box of all meshes (margin of the top-level walk)
+  const CADDR DTri *tris;
+  const CADDR DNode *nodes;    // top-level tree over the meshes (two-wide nodes)
+  const CADDR DNode4 *nodes4;  // per-mesh trees (four-wide nodes)
   const CADDR DCam *cams;      // one camera per frame of the batch (all w x h)
   uint32_t w, h;
   uint32_t first_frame, n_frames;
   uint64_t frame_stride_px;    // pixels between consecutive frames in the output buffers
   DRows rows;
   float fudge;
-  int bounces;
-  uint32_t has_mesh;
   uint32_t nf;        // LDS dwords per stack frame: 4, or 10 when some material reflects AND transmits
   uint32_t frames;    // LDS stack frames per lane: the recursion depth that can be reached (bounces, or 1 when no
                       // material reflects or transmits: ray_color then never recurses)
@@ -286,6 +305,9 @@ struct KArgs {
   uint32_t *group_done;
   float *uv_out;      // KV_UV: texture coordinates of the primary hit, 2 floats per pixel
 };
+
+static_assert(offsetof(KArgs, planes) == 0 && offsetof(KArgs, has_mesh) == 28, "KArgs: the hot block is the first eight dwords");
+static_assert(offsetof(KArgs, objs) == 32 && offsetof(KArgs, mats) == 56 && offsetof(KArgs, bounces) == 68, "KArgs: the cold block follows");
 
 // ---- Host delivery ----
 // ctr_render hands the kernel page-locked HOST buffers.  Storing the pixels there tile by tile works (the memory is
@@ -465,6 +487,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   const CADDR KArgs *AK = (const CADDR KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   while (BALLOT(MSP_ACTIVE(msp)) != 0ull) {
     asm volatile("" : "+s"(AK));
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    const u32x8 hot = *(const CADDR u32x8 *)AK;  // KArgs' hot block
+    const CADDR DPlanePair *const k_planes = (const CADDR DPlanePair *)(((uint64_t)hot[1] << 32) | hot[0]);
+    const uint32_t k_plane_recs = hot[2], k_axis_recs = hot[3], k_n_oloop = hot[4], k_mesh = hot[5], k_tlas_root = hot[6];
+    const bool k_has_mesh = hot[7] != 0u;
     TSTAMP(t_trip0);
     CTR_MARK(1);  // trip head: cast set-up
     const bool active = MSP_ACTIVE(msp);
@@ -483,7 +510,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     V3 ria = mk(0, 0, 0);
     float ria_big = 0.f;
     float cmax = 0.f;
-    if (AK->has_mesh) {
+    if (k_has_mesh) {
       CTR_MARK(2);
       // 1-ulp reciprocals, clamped to +-1e30: an axis-parallel ray (d = 0 -> inf) then gives huge
       // FINITE slab distances with the right signs instead of inf - inf = NaN
@@ -560,28 +587,49 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         num = (dx * nx + dy * ny) + dz * nz;
         den = (rdx * nx + rdy * ny) + rdz * nz;
       };
-      const uint32_t n_pairs = (AK->n_planes + 1u) >> 1;
-      for (uint32_t p = 0; p < n_pairs;) {
-        if (n_pairs - p >= 3u) {
-          CTR_MARK(6);  // three plane records
-          const CADDR DPlanePair &P0 = AK->planes[p], &P1 = AK->planes[p + 1], &P2 = AK->planes[p + 2];
+      // Axis-aligned planes (the first n_axis_recs records, whole triples: two planes normal to x, two to y, two to z):
+      // the reference's  dx*nx + dy*ny + dz*nz  with two of the normal's components zero is the one product that is
+      // not multiplied by zero whenever that product is not zero itself (x + (+-0) = x), and a zero of either sign
+      // otherwise.  A zero numerator gives t0 = +-0 or NaN and a zero denominator an infinite or NaN t0 — a miss
+      // whatever the zero's sign as long as min_t > 0; so with fudge > 0 and every live lane's origin and direction
+      // finite (0 x inf would be NaN in the reference) three packed instructions per record stand for thirteen.
+      const uint32_t n_recs = k_plane_recs, n_axis = k_axis_recs;
+      bool axis_fast = false;  // wave-uniform
+      if (n_axis != 0u && A.fudge >= 1e-30f) {
+        CTR_MARK(4);
+        // NaN iff some component is not finite (or the sum overflows: then the general code, which is always right)
+        const float chk = (((((ro.x + ro.y) + ro.z) + rd.x) + rd.y) + rd.z) * 0.0f;
+        axis_fast = BALLOT(live && !(chk == 0.0f)) == 0ull;
+      }
+      for (uint32_t p = 0; p < n_recs;) {
+        if (n_recs - p >= 3u) {
+          const CADDR DPlanePair &P0 = k_planes[p], &P1 = k_planes[p + 1], &P2 = k_planes[p + 2];
           float2_ num0, den0, num1, den1, num2, den2;
-          num_den(P0, num0, den0);
-          num_den(P1, num1, den1);
-          num_den(P2, num2, den2);
+          // (indices first: their loads then travel with the coordinates', one round trip for the triple)
           const uint32_t i00 = P0.index[0], i01 = P0.index[1], i10 = P1.index[0], i11 = P1.index[1], i20 = P2.index[0],
                          i21 = P2.index[1];
-          p += 3;
-          if (!plane_test(i00, num0.x, den0.x, SITE(0))) break;
-          if (!plane_test(i01, num0.y, den0.y, SITE(1))) break;   // (only the LAST record of the array can hold a padding slot)
-          if (!plane_test(i10, num1.x, den1.x, SITE(2))) break;
-          if (!plane_test(i11, num1.y, den1.y, SITE(3))) break;
-          if (!plane_test(i20, num2.x, den2.x, SITE(4))) break;
-          if (i21 != CTR_PLANE_PAD) {
-            if (!plane_test(i21, num2.y, den2.y, SITE(5))) break;
+          if (p < n_axis && axis_fast) {
+            CTR_MARK(5);  // an axis triple
+            const float2_ nx = ldpair(P0.n[0]), ny = ldpair(P1.n[1]), nz = ldpair(P2.n[2]);
+            num0 = (ldpair(P0.p[0]) - rox) * nx; den0 = rdx * nx;
+            num1 = (ldpair(P1.p[1]) - roy) * ny; den1 = rdy * ny;
+            num2 = (ldpair(P2.p[2]) - roz) * nz; den2 = rdz * nz;
+          } else {
+            CTR_MARK(6);  // three plane records
+            num_den(P0, num0, den0);
+            num_den(P1, num1, den1);
+            num_den(P2, num2, den2);
           }
+          p += 3;
+          // (a slot without a plane: CTR_PLANE_PAD)
+          if (i00 != CTR_PLANE_PAD) { if (!plane_test(i00, num0.x, den0.x, SITE(0))) break; }
+          if (i01 != CTR_PLANE_PAD) { if (!plane_test(i01, num0.y, den0.y, SITE(1))) break; }
+          if (i10 != CTR_PLANE_PAD) { if (!plane_test(i10, num1.x, den1.x, SITE(2))) break; }
+          if (i11 != CTR_PLANE_PAD) { if (!plane_test(i11, num1.y, den1.y, SITE(3))) break; }
+          if (i20 != CTR_PLANE_PAD) { if (!plane_test(i20, num2.x, den2.x, SITE(4))) break; }
+          if (i21 != CTR_PLANE_PAD) { if (!plane_test(i21, num2.y, den2.y, SITE(5))) break; }
         } else {
-          const CADDR DPlanePair &P0 = AK->planes[p];
+          const CADDR DPlanePair &P0 = k_planes[p];
           CTR_MARK(7);  // one plane record
           float2_ num0, den0;
           num_den(P0, num0, den0);
@@ -604,7 +652,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     V3 sph_d = mk(0, 0, 0);
     float sph_dd = 0.f;
     bool sph_have = false;  // wave-uniform
-    for (uint32_t oi = 0; oi < AK->n_oloop; ++oi) {
+    for (uint32_t oi = 0; oi < k_n_oloop; ++oi) {
       if (ANYHIT) {
         if (BALLOT(live) == 0ull) break;
       }
@@ -672,8 +720,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     TSTAMP(t_oloop1);
     TACC(2, t_planes1, t_oloop1);
     CTR_MARK(13);
-    if (AK->n_mesh != 0u) {
-      uint32_t t_pend = AK->tlas_root;           // next top-level item: inner node or mesh leaf
+    if (k_mesh != 0u) {
+      uint32_t t_pend = k_tlas_root;             // next top-level item: inner node or mesh leaf
       uint32_t t_stack_v = 0, t_sp = 0;        // wave-uniform stack in the lanes of one VGPR
       for (;;) {
         TSTAMP(t_tl0);
@@ -716,9 +764,13 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             // visiting order as in the per-mesh walk (speed only): along the lead ray for nearest-hit casts, against
             // it for any-hit shadow casts
             const bool t_rev = ((t_neg >> N.axis) & 1u) != 0u;
+            // (both children are VALUES here, fetched with the boxes: the compiler otherwise selects the ADDRESS and loads
+            //  the one it wants after the test — a second dependent round trip per node)
+            uint32_t n_left = N.left, n_right = N.right;
+            asm volatile("" : "+s"(n_left), "+s"(n_right));
             const bool h0 = t_hits(0) != 0ull, h1 = t_hits(1) != 0ull;
             const bool hl = t_rev ? h1 : h0, hr = t_rev ? h0 : h1;
-            const uint32_t dl = t_rev ? N.right : N.left, dr = t_rev ? N.left : N.right;
+            const uint32_t dl = t_rev ? n_right : n_left, dr = t_rev ? n_left : n_right;
             if (hl && hr) {
               t_stack_v = ctr_writelane(__builtin_amdgcn_readfirstlane(dr),
                                                        __builtin_amdgcn_readfirstlane(t_sp), t_stack_v);
@@ -748,6 +800,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         }
         CTR_MARK(17);  // a mesh: AABB test
         const uint32_t i = O.index;
+        // (the whole record in one round trip: what the walk needs is requested with the box, not after its test)
+        const uint32_t o_tri_begin = O.tri_begin, o_tri_count = O.tri_count, o_node_begin = O.node_begin, o_bvh_root = O.bvh_root;
         bool ok = false;
         float cand = INFINITY;
         int ctri = -1;
@@ -805,7 +859,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           if (bb_m == 0ull) continue;  // no lane of this wave needs the mesh
           const mask_t bb0_m = bb_m;
           CTR_MARK(22);  // mesh entered: walk set-up
-          const uint32_t beg = O.tri_begin, cnt = O.tri_count;
+          const uint32_t beg = o_tri_begin, cnt = o_tri_count;
           if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
           if (STATS) st[4]++;
           uint32_t pl_nodes = 0, pl_tris = 0;  // STATS: this lane's own share of the mesh entry's node visits / triangle tests
@@ -823,12 +877,12 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 
           const float2_ ro_xy = {ro.x, ro.y};
           // one triangle against the lanes in `lanes_m` (wave-uniform T: SGPR operands)
-          auto tri_test = [&](const auto &T, uint32_t tri_index, mask_t lanes_m) {
+          auto tri_test = [&](const TriR &T, uint32_t tri_index, mask_t lanes_m) {
             CTR_MARK(23);  // triangle: prefilter stage 1
             mask_t c_m = lanes_m;
             if (STATS) { st[2]++; st[7] += __builtin_popcountll(lanes_m); pl_tris += INVB(lanes_m) ? 1u : 0u; }
             // d = p2 - start (default_schema.hpp:58): x and y in one packed subtraction (same IEEE result)
-            const float2_ dxy = ldpair2(&T.px) - ro_xy;
+            const float2_ dxy = T.pxy - ro_xy;
             const float dx = dxy.x, dy = dxy.y, dz = T.pz - ro.z;
             uint32_t sgn = 0;
             float sA1 = 0.f, sA2 = 0.f, absa = 0.f, dmax = 0.f, E = 0.f;
@@ -847,9 +901,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               q_z.y = 0.0f;
               // (a.q, b.q) = (A2, -A1) together: the (a, b) pairs of the record times q, three packed instructions
               float2_ m;
-              PKMULB(m, ldpair(T.ab[0]), q_xy, 0);
-              PKFMAB(m, ldpair(T.ab[1]), q_xy, 1, m);
-              PKFMAB(m, ldpair(T.ab[2]), q_z, 0, m);
+              PKMULB(m, T.ab0, q_xy, 0);
+              PKFMAB(m, T.ab1, q_xy, 1, m);
+              PKFMAB(m, T.ab2, q_z, 0, m);
               // (s A2, s A1) with s = sign(alpha): multiply by (s, -s), exact
               sgn = __float_as_uint(alpha) & 0x80000000u;
               float2_ s1;
@@ -920,7 +974,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             if (INVB(c_m)) {
               // ---- triangle::intersect, default_schema.hpp:57-78: the four determinants in the
               //      reference's operation order ----
-              const V3 a = mk(T.ab[0][0], T.ab[1][0], T.ab[2][0]), b = mk(T.ab[0][1], T.ab[1][1], T.ab[2][1]);
+              const V3 a = mk(T.ab0.x, T.ab1.x, T.ab2.x), b = mk(T.ab0.y, T.ab1.y, T.ab2.y);
               const V3 d = mk(dx, dy, dz);
               const float alpha = det3(a, b, rd);
               const float A1 = det3(d, b, rd), A2 = det3(a, d, rd), A0 = det3(a, b, d);
@@ -1000,7 +1054,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             const float mw = fmaxf(fmaxf(gx, gy), gz) * 0x1p-14f;
             const V3 ka = mk((ro.x + mw) * ria.x, (ro.y + mw) * ria.y, (ro.z + mw) * ria.z);  // for box minima
             const V3 kb = mk((ro.x - mw) * ria.x, (ro.y - mw) * ria.y, (ro.z - mw) * ria.z);  // for box maxima
-            const CADDR DNode4 *nodes4 = A.nodes4 + O.node_begin;
+            const CADDR DNode4 *nodes4 = A.nodes4 + o_node_begin;
             // direction signs of the first lane that needs the mesh decide the visiting order (speed only)
             const uint32_t lead = (uint32_t)__builtin_ctzll(bb_m);
             // (readlane returns int: shift its bits as unsigned — only bits 0..2 are used below, but an arithmetic shift
@@ -1042,11 +1096,30 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               TSTAMP(t_leaf0);
               CTR_MARK(80);  // a leaf's triangles
               const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
-              for (uint32_t k = 0; k < n_l; ++k) {
-                tri_test(A.tris[first + k], first + k, lanes & bb_m);
+              // The leaf's first triangle is fetched as one 64-byte record, and one dword of each of the next three cache
+              // lines is requested with it, into a register nobody reads ("touch"): the loads of the leaf's other triangles —
+              // one dependent round trip each — then find their lines in the scalar cache.  64 000 triangles -3 %, first
+              // launch -5 %; a 1 000-triangle mesh, which stays in the scalar cache anyway, +-0.5 %
+              // (profiles/r03/exp_leaf_touch.txt).  The wait is part of the statement, so the unread register is dead when it
+              // ends.  (ctr_api.cpp allocates 256 bytes beyond every array for requests past the last triangle.)
+              if (n_l == 0u) return;
+              typedef uint32_t u32x16_ __attribute__((ext_vector_type(16)));
+              u32x16_ t0;
+              uint32_t touch_;
+              asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_load_dword %1, %2, 0x80\n\ts_load_dword %1, %2, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                           : "=&s"(t0), "=&s"(touch_) : "s"(&A.tris[first]));
+              TriR cur;
+              cur.ab0.x = __uint_as_float(t0[0]); cur.ab0.y = __uint_as_float(t0[1]); cur.ab1.x = __uint_as_float(t0[2]); cur.ab1.y = __uint_as_float(t0[3]);
+              cur.ab2.x = __uint_as_float(t0[4]); cur.ab2.y = __uint_as_float(t0[5]); cur.pxy.x = __uint_as_float(t0[6]); cur.pxy.y = __uint_as_float(t0[7]);
+              cur.pz = __uint_as_float(t0[8]); cur.orig = t0[9]; cur.nx = __uint_as_float(t0[10]); cur.ny = __uint_as_float(t0[11]);
+              cur.nz = __uint_as_float(t0[12]); cur.ke = __uint_as_float(t0[13]); cur.ke2 = __uint_as_float(t0[14]);
+              for (uint32_t k = 0;;) {
+                tri_test(cur, first + k, lanes & bb_m);
                 if (ANYHIT) {
                   if (bb_m == 0ull) break;
                 }
+                if (++k >= n_l) break;
+                cur = load_tri(A.tris[first + k]);
               }
 #ifdef CTR_TIMING
               t_leaves += __builtin_readcyclecounter() - t_leaf0;
@@ -1062,7 +1135,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             // node 0 is the root (a mesh that fits one leaf has a root with one child).  A mesh with guard
             // records (triangles every lane must meet whatever their box, ctr_api.cpp refresh_linear_meshes)
             // starts one node earlier, at an extra node whose children are the guard leaf and the root.
-            uint32_t cur = O.bvh_root;
+            uint32_t cur = o_bvh_root;
 #ifdef CTR_TIMING
             t_w0 = __builtin_readcyclecounter();
             tm[4] += t_w0 - t_bb;
@@ -1074,11 +1147,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               mask_t h0, h1, h2, h3;
               box_hits2(N, 0, h0, h1);
               box_hits2(N, 2, h2, h3);
+              const uint32_t d0 = N.child[0], d1 = N.child[1], d2 = N.child[2], d3 = N.child[3], n_axis_ = N.axis;
               if (STATS) { st[6] += __builtin_popcountll(h0 | h1 | h2 | h3); pl_nodes += INVB(h0 | h1 | h2 | h3) ? 1u : 0u; }
-              const uint32_t d0 = N.child[0], d1 = N.child[1], d2 = N.child[2], d3 = N.child[3];
               // children are stored sorted along the node's order axis; a wave whose lead ray points the other
               // way takes them in reverse (wave-uniform selects): e0/g0 = nearest ... e3/g3 = farthest
-              const bool rev = ((neg_bits >> N.axis) & 1u) != 0u;
+              const bool rev = ((neg_bits >> n_axis_) & 1u) != 0u;
               const uint32_t e0 = rev ? d3 : d0, e1 = rev ? d2 : d1, e2 = rev ? d1 : d2, e3 = rev ? d0 : d3;
               const mask_t g0 = rev ? h3 : h0, g1 = rev ? h2 : h1, g2 = rev ? h1 : h2, g3 = rev ? h0 : h3;
               // ONE pass, farthest child first: a hit leaf is tested at once; a hit inner child becomes the node to
@@ -1120,7 +1193,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             }
           } else {
             for (uint32_t k = 0; k < cnt; ++k) {
-              tri_test(A.tris[beg + k], beg + k, bb_m);  // wave-uniform: one s_load_dwordx16
+              tri_test(load_tri(A.tris[beg + k]), beg + k, bb_m);  // wave-uniform: one s_load_dwordx16
               if (ANYHIT) {
                 if (bb_m == 0ull) break;
               }
@@ -1168,6 +1241,17 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     // =====================================================================
     // continuation: what did this lane cast the ray for?
     // =====================================================================
+    // the continuation's kernel arguments in ONE round trip (pointer by pointer, each was a scalar load the wave waited
+    // for before it could even request the record behind it)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x8 cold = *(const CADDR u32x8 *)&AK->objs;
+    const u32x4 cold2 = *(const CADDR u32x4 *)&AK->n_light;
+    const CADDR DObj *const k_objs = (const CADDR DObj *)(((uint64_t)cold[1] << 32) | cold[0]);
+    const CADDR float *const k_gnorm = (const CADDR float *)(((uint64_t)cold[3] << 32) | cold[2]);
+    const CADDR DLight *const k_lights = (const CADDR DLight *)(((uint64_t)cold[5] << 32) | cold[4]);
+    const CADDR DMat *const k_mats = (const CADDR DMat *)(((uint64_t)cold[7] << 32) | cold[6]);
+    const uint32_t k_n_light = cold2[0];
+    const int k_bounces = (int)cold2[1];
     int act = ACT_NONE;
     float first_depth = 0.f;  // primary-hit depth of this lane, alive in the first trip only
     if (MSP_IS_RADIANCE(msp)) {
@@ -1175,20 +1259,25 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       V3 normal = mk(0, 0, 0);
       float tc_u = 0.0f, tc_v = 0.0f;  // (UV) uv{} of kernel.hpp:51 on a miss
       if (was_hit) {
-        const CADDR DObj &H = AK->objs[bobj];
+        const CADDR DObj &H = k_objs[bobj];
         CTR_MARK(37);  // hit record
+        // (type, material, the six floats and the triangle's normal are requested together, before the type decides
+        //  which of them is used: one vector-memory round trip instead of two)
+        const uint32_t ht = H.type;
+        const float hf0 = H.f[0], hf1 = H.f[1], hf2 = H.f[2], hf3 = H.f[3], hf4 = H.f[4], hf5 = H.f[5];
+        float gn0 = 0.f, gn1 = 0.f, gn2 = 0.f;
+        if (btri >= 0) { gn0 = k_gnorm[4 * btri + 0]; gn1 = k_gnorm[4 * btri + 1]; gn2 = k_gnorm[4 * btri + 2]; }  // (a scene without triangles has no such array)
         mat_i = H.mat;
         pos = vadd(ro, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
         float unused_n0;
         const V3 hit_dn = vnormalized_n(in_d, unused_n0);
         CTR_MARK(92);
         set_in_dn(hit_dn);
-        const uint32_t ht = H.type;
         if (ht == CTR_OBJ_SPHERE) {
           CTR_MARK(38);
           // default_schema.hpp:245-246: hit uses the NORMALIZED direction
           const V3 hit = vadd(ro, vscale(hit_dn, best));
-          normal = vnormalized(vsub(hit, mk(H.f[0], H.f[1], H.f[2])));
+          normal = vnormalized(vsub(hit, mk(hf0, hf1, hf2)));
           ro = hit;
           if (UV && first_trip) {  // default_schema.hpp:246-249: delta = (hit - center).normalized() is the normal again
             tc_u = 0.5f + (atan2f(normal.z, normal.x) / (2.0f * (float)M_PI));
@@ -1196,24 +1285,24 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           }
         } else if (ht == CTR_OBJ_PLANE) {
           ro = pos;
-          normal = mk(H.f[3], H.f[4], H.f[5]);
+          normal = mk(hf3, hf4, hf5);
           if (UV && first_trip) {  // plane::uv_for, default_schema.hpp:169-178
             const V3 ax1 = vnormalized(mk(normal.y, -normal.x, 0.0f));
             const V3 ax2 = vcross(normal, ax1);
-            const V3 mod_pt = vsub(mk(H.f[0], H.f[1], H.f[2]), pos);
+            const V3 mod_pt = vsub(mk(hf0, hf1, hf2), pos);
             tc_u = vdot(ax1, mod_pt);
             tc_v = vdot(ax2, mod_pt);
           }
         } else {
           ro = pos;
-          normal = mk(AK->gnorm[4 * btri + 0], AK->gnorm[4 * btri + 1], AK->gnorm[4 * btri + 2]);
+          normal = mk(gn0, gn1, gn2);
           if (UV && first_trip) {
             if (ht == CTR_OBJ_MESH) {  // mesh::intersect, default_schema.hpp:138-139
               tc_u = pos.x;
               tc_v = pos.y;
             } else {                   // triangle::uv_for, default_schema.hpp:37-46
               const CADDR DTri &T = A.tris[btri];
-              const V3 p1 = mk(H.f[0], H.f[1], H.f[2]), p2 = mk(T.px, T.py, T.pz), p3 = mk(H.f[3], H.f[4], H.f[5]);
+              const V3 p1 = mk(hf0, hf1, hf2), p2 = mk(T.px, T.py, T.pz), p3 = mk(hf3, hf4, hf5);
               const V3 p2p1 = vsub(p2, p1), p3p1 = vsub(p3, p1), xp1 = vsub(pos, p1);
               const V3 proj_u = vscale(p2p1, vdot(xp1, p2p1) / vdot(p2p1, p2p1));
               const V3 proj_v = vscale(p3p1, vdot(xp1, p3p1) / vdot(p3p1, p3p1));
@@ -1245,7 +1334,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       } else {
         // phong prologue, shading.hpp:66-76
         CTR_MARK(42);
-        const CADDR DMat &M = AK->mats[mat_i];
+        const CADDR DMat &M = k_mats[mat_i];
         fin = vscale(mk(M.cx, M.cy, M.cz), ambient);
         { float unused_n; const V3 nrm_ = vnormalized_n(normal, unused_n); CTR_MARK(93); set_nn(nrm_); }
         li = 0;
@@ -1258,7 +1347,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       float shadow_fac = 0.f;
       if (was_hit && best < light_dist) {
         // scenes without any transparency (the any-hit builds) need no material lookup here
-        const float trans = ANYHIT ? 0.0f : AK->mats[AK->objs[bobj].mat].transparency;
+        const float trans = ANYHIT ? 0.0f : k_mats[k_objs[bobj].mat].transparency;
         if (!ANYHIT) intensity += (1.0f - trans);
         if (ANYHIT || intensity >= 1.0f) { shadow_fac = 1.0f; done_shadow = true; }
         else {
@@ -1273,8 +1362,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         if (shadow_fac < 1.0f) {
           // shading.hpp:86-95
           CTR_MARK(44);  // shade one light
-          const CADDR DMat &M = AK->mats[mat_i];
-          const CADDR DLight &Lg = AK->lights[li];
+          const CADDR DMat &M = k_mats[mat_i];
+          const CADDR DLight &Lg = k_lights[li];
           const V3 diffuse = mk(M.cx, M.cy, M.cz);
           const V3 specular = vscale(diffuse, M.specular);  // default_schema.hpp:328
           const V3 color = mk(Lg.cx, Lg.cy, Lg.cz);
@@ -1308,18 +1397,20 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     TACC(7, t_loop1, t_cont_mid);
     CTR_MARK(46);
     if (act == ACT_LIGHT) {
-      if (li < AK->n_light) {
+      if (li < k_n_light) {
         // shading.hpp:79-85: direction/distance to light li, shadow ray from *hit
         CTR_MARK(47);  // next light
-        const CADDR DLight &Lg = AK->lights[li];
+        const CADDR DLight &Lg = k_lights[li];
+        const uint32_t lg_type = Lg.type;
+        const V3 lg_v = mk(Lg.vx, Lg.vy, Lg.vz);  // (with the type: one 16-byte load)
         V3 direction;
         float distance;
-        if (Lg.type == CTR_LIGHT_SUN) {  // default_schema.hpp:280-283
-          direction = vscale(mk(Lg.vx, Lg.vy, Lg.vz), -1.0f);
+        if (lg_type == CTR_LIGHT_SUN) {  // default_schema.hpp:280-283
+          direction = vscale(lg_v, -1.0f);
           distance = INFINITY;
         } else {                         // default_schema.hpp:305-308
           CTR_MARK(48);  // point light
-          const V3 diff = vsub(mk(Lg.vx, Lg.vy, Lg.vz), ro);  // ro == *hit
+          const V3 diff = vsub(lg_v, ro);  // ro == *hit
           direction = vnormalized_n(diff, distance);
           CTR_MARK(94);
         }
@@ -1339,10 +1430,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     if (act == ACT_BOUNCE) {
       // shading.hpp:126-150 with rgb = fin
       CTR_MARK(50);
-      const CADDR DMat &M = AK->mats[mat_i];
+      const CADDR DMat &M = k_mats[mat_i];
       const float reflective = M.reflexivity, translucent = M.transparency;
       const int sp = MSP_DEPTH(msp);
-      const bool more = sp < AK->bounces;  // `if constexpr (bounces != 0)`
+      const bool more = sp < k_bounces;  // `if constexpr (bounces != 0)`
       const bool do_refl = more && (double)reflective >= 1e-6;
       const bool do_trans = more && (double)translucent >= 1e-6;
       if (do_refl || do_trans) {
@@ -1384,7 +1475,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         --sp;
         V3 rgb = mk(STK(sp, F_R), STK(sp, F_G), STK(sp, F_B));
         const uint32_t f_mat = __float_as_uint(STK(sp, F_MAT));
-        const CADDR DMat &FM = AK->mats[f_mat & 0x3FFFFFFFu];
+        const CADDR DMat &FM = k_mats[f_mat & 0x3FFFFFFFu];
         const float f_transl = FM.transparency;
         if ((f_mat >> 30) == 1u) {
           CTR_MARK(97);
@@ -1799,7 +1890,8 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   for (int q = 0; q < 3; q++) { A.tl_mn[q] = L.tl_mn[q]; A.tl_mx[q] = L.tl_mx[q]; }
   A.planes = (const CADDR DPlanePair *)L.planes;
   A.n_oloop = L.n_oloop;
-  A.n_planes = L.n_planes;
+  A.n_plane_recs = L.n_plane_recs;
+  A.n_axis_recs = L.n_axis_recs;
   A.tris = (const CADDR DTri *)L.tris;
   A.nodes = (const CADDR DNode *)L.nodes;
   A.nodes4 = (const CADDR DNode4 *)L.nodes4;

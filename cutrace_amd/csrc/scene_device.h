@@ -62,8 +62,14 @@ static_assert(sizeof(DObj) == 64, "DObj must be 64 bytes");
 // cast visits every one of them.  Two planes share one 64-byte record with their coordinates
 // interleaved, so that (plane 0, plane 1) of one coordinate is an aligned SGPR pair and the two
 // numerators / denominators are evaluated with packed f32 instructions — same multiplies and adds in
-// the same order as the scalar form, two at a time.  An odd plane count pads the last record with a
-// copy of its first plane (index[1] = CTR_PLANE_PAD: never tested).
+// the same order as the scalar form, two at a time.  A slot without a plane holds harmless numbers and
+// index = CTR_PLANE_PAD (never tested).
+// Axis-aligned planes (exactly one non-zero normal component: the walls of a box room) come first, in whole TRIPLES
+// of records: record 0 of a triple holds up to two planes normal to x, record 1 to y, record 2 to z (n_axis_recs, a
+// multiple of 3).  For those the kernel forms (point - origin).normal and dir.normal from the one component that
+// is not multiplied by zero — three packed instructions per record instead of thirteen, the same bits whenever the
+// value can matter (render_kernel.hip, "axis-aligned planes").  The records are complete, so the general code gives
+// the reference's arithmetic on them as well.
 struct DPlanePair {
   float p[3][2];        // point:  p[axis][which plane]
   float n[3][2];        // normal
@@ -123,8 +129,8 @@ struct RenderLaunch {
   const DObj *meshes;      // non-empty meshes in top-level-BVH leaf order
   uint32_t n_mesh, tlas_root, tlas_begin;
   float tl_mn[3], tl_mx[3];
-  const DPlanePair *planes;  // ceil(n_planes / 2) records
-  uint32_t n_oloop, n_planes;
+  const DPlanePair *planes;  // n_plane_recs records, the first n_axis_recs of them axis triples
+  uint32_t n_oloop, n_plane_recs, n_axis_recs;
   const DTri *tris;
   const void *nodes;    // DNode[] (bvh.h): top-level tree over the meshes
   const void *nodes4;   // DNode4[] (bvh.h): per-mesh trees

@@ -767,3 +767,54 @@ def test_texture_coordinates_random_scenes_vs_oracle(ca):
         r = ca.DeviceScene(s).render_uv(bounces=1)
         _uv_close(r["uv"], o["uv"])
         assert same_bits(r["depth"], o["depth"]) and same_bits(r["normal"], o["normal"])
+
+
+def _axis_plane_scene(case, w=64, h=40):
+    """Scenes for the axis-aligned plane path (render_kernel.hip "axis-aligned planes"; scene_device.h DPlanePair)."""
+    import json
+    mats = [{"type": "solid", "color": [0.9, 0.3, 0.2], "specular": 0.4, "reflect": 0.5, "phong": 20.0, "transparency": 0.0},
+            {"type": "solid", "color": [0.2, 0.8, 0.3], "specular": 0.1, "reflect": 0.0, "phong": 1.0, "transparency": 0.0},
+            {"type": "solid", "color": [0.3, 0.3, 0.9], "specular": 0.7, "reflect": 0.3, "phong": 300.0,
+             "transparency": 0.5 if case in ("many_per_axis", "underflow") else 0.0}]
+    lights = [{"type": "point", "point": [0.5, 1.5, -1.0], "color": [1, 1, 1]}, {"type": "sun", "direction": [0.3, -1, 0.2], "color": [0.5, 0.5, 0.4]}]
+    eye = [0.0, 0.0, -3.5]
+    objs = [{"type": "sphere", "center": [0.3, -0.2, 0.5], "radius": 0.8, "material": 0}]
+    if case in ("box", "eye_on_plane", "fudge_zero", "fudge_negative"):
+        # a closed room; zeros of both signs in the normals; the middle column of an even-width image has dir.x == 0
+        objs += [{"type": "plane", "point": [-3, 0, 0], "normal": [1, -0.0, 0], "material": 1},
+                 {"type": "plane", "point": [3, 0, 0], "normal": [-1, 0, -0.0], "material": 2},
+                 {"type": "plane", "point": [0, -2, 0], "normal": [-0.0, 1, 0], "material": 1},
+                 {"type": "plane", "point": [0, 2.5, 0], "normal": [0, -2, -0.0], "material": 0},
+                 {"type": "plane", "point": [0, 0, 4], "normal": [0, 0, -1], "material": 2},
+                 {"type": "plane", "point": [0, 0, -4], "normal": [-0.0, -0.0, 0.5], "material": 1}]
+        if case == "eye_on_plane":
+            eye = [0.0, -2.0, -3.5]  # on the floor plane: a zero numerator for every primary ray
+    elif case == "one_axis_only":
+        objs += [{"type": "plane", "point": [0, -1.5, 0], "normal": [0, 1, 0], "material": 1},
+                 {"type": "plane", "point": [1, 0, 5], "normal": [0.2, 0.1, -1], "material": 2}]
+    elif case == "many_per_axis":
+        # five planes normal to y (three triples), one to x, two general ones, some transparent (the ordered shadow loop)
+        for k, y in enumerate((-1.0, -1.5, -2.5, 3.0, 4.0)):
+            objs.append({"type": "plane", "point": [k, y, -k], "normal": [0, 1.0 if y < 0 else -3.0, 0], "material": k % 3})
+        objs += [{"type": "plane", "point": [4, 0, 0], "normal": [-1, 0, 0], "material": 2},
+                 {"type": "plane", "point": [0, 0, 6], "normal": [0.1, 0, -1], "material": 1},
+                 {"type": "plane", "point": [-5, 0, 0], "normal": [1, 0.05, 0.02], "material": 0}]
+    elif case == "underflow":
+        # normals so short that products underflow to zeros and denormals
+        objs += [{"type": "plane", "point": [0, -1.5, 0], "normal": [0, 1e-38, 0], "material": 1},
+                 {"type": "plane", "point": [0, 0, 5], "normal": [0, 0, -1e-30], "material": 2},
+                 {"type": "plane", "point": [-3, 1e-9, 0], "normal": [3e-39, 0, 0], "material": 0}]
+    cam = {"eye": eye, "up": [0, 1, 0], "look": [eye[0], eye[1], 0.0], "near_plane": 0.1, "far_plane": 100.0, "width": w, "height": h,
+           "ambient": 0.15}
+    return json.dumps({"camera": cam, "lights": lights, "materials": mats, "objects": objs})
+
+
+@pytest.mark.parametrize("case", ["box", "eye_on_plane", "one_axis_only", "many_per_axis", "underflow", "fudge_zero", "fudge_negative"])
+def test_axis_aligned_planes(gpu, case):
+    """Planes with exactly one non-zero normal component take a three-instruction path for numerator and denominator
+    (the products with zero left out); with fudge <= 0 the kernel must fall back to the reference's full expression
+    (a zero's sign could then decide).  Everything against the oracle, and bitwise against the kernel without shortcuts."""
+    s = gpu.HostScene.parse(_axis_plane_scene(case))
+    assert s.ok, s.error
+    fudge = {"fudge_zero": 0.0, "fudge_negative": -0.25}.get(case, 1e-3)
+    _check_all_ways(gpu, s, f"axis-aligned planes: {case}", bounces=3, fudge=fudge)
