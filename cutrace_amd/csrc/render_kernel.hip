@@ -1254,6 +1254,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     const int k_bounces = (int)cold2[1];
     int act = ACT_NONE;
     float first_depth = 0.f;  // primary-hit depth of this lane, alive in the first trip only
+    // the light the NEXT shadow ray goes to (type and position / direction), requested together with whatever else this
+    // continuation reads first — the hit record, or the material and light being shaded — instead of in a round trip of its
+    // own afterwards.  (lights[n_light] is inside the allocation: ctr_api.cpp pads every array.)
+    uint32_t nl_type = 0u;
+    V3 nl_v = mk(0.f, 0.f, 0.f);
     if (MSP_IS_RADIANCE(msp)) {
       // ---- hit record: hit point, normal (per primitive), material ----
       V3 normal = mk(0, 0, 0);
@@ -1268,6 +1273,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         float gn0 = 0.f, gn1 = 0.f, gn2 = 0.f;
         if (btri >= 0) { gn0 = k_gnorm[4 * btri + 0]; gn1 = k_gnorm[4 * btri + 1]; gn2 = k_gnorm[4 * btri + 2]; }  // (a scene without triangles has no such array)
         mat_i = H.mat;
+        { const CADDR DLight &L0 = k_lights[0]; nl_type = L0.type; nl_v = mk(L0.vx, L0.vy, L0.vz); }
         pos = vadd(ro, vscale(in_d, best));  // start + dist*dir (triangle/plane hit; shading.hpp:133,143)
         float unused_n0;
         const V3 hit_dn = vnormalized_n(in_d, unused_n0);
@@ -1343,6 +1349,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     } else if (MSP_IS_SHADOW(msp)) {
       // ---- one iteration of shadow_intensity's loop, shading.hpp:32-42 ----
       CTR_MARK(43);
+      { const CADDR DLight &L1 = k_lights[li + 1u]; nl_type = L1.type; nl_v = mk(L1.vx, L1.vy, L1.vz); }
       bool done_shadow;
       float shadow_fac = 0.f;
       if (was_hit && best < light_dist) {
@@ -1400,9 +1407,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       if (li < k_n_light) {
         // shading.hpp:79-85: direction/distance to light li, shadow ray from *hit
         CTR_MARK(47);  // next light
-        const CADDR DLight &Lg = k_lights[li];
-        const uint32_t lg_type = Lg.type;
-        const V3 lg_v = mk(Lg.vx, Lg.vy, Lg.vz);  // (with the type: one 16-byte load)
+        const uint32_t lg_type = nl_type;
+        const V3 lg_v = nl_v;
         V3 direction;
         float distance;
         if (lg_type == CTR_LIGHT_SUN) {  // default_schema.hpp:280-283
