@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                   if (bb_m == 0ull) break;
                 }
                 if (++k >= n_l) break;
+                CTR_MARK(82);  // the leaf's next triangle
                 cur = load_tri(A.tris[first + k]);
               }
 #ifdef CTR_TIMING
