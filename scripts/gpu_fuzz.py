@@ -18,7 +18,7 @@ t0 = time.time()
 for seed in range(first, first + count):
     opaque = seed % 2 == 0
     w, h = [(88, 56), (61, 37), (130, 24), (64, 64)][(seed // 6) % 4]   # ragged right / bottom tiles and tile groups
-    s = ca.HostScene.parse(_random_scene(seed, w=w, h=h, opaque_mesh=opaque))
+    s = ca.HostScene.parse(_random_scene(seed, w=w, h=h, opaque_mesh=opaque, extra_planes=seed % 3 != 0))  # (walls of all kinds: the axis-aligned plane path)
     assert s.ok
     b = [0, 1, 2, 3, 5, 7][seed % 6]
     ds = ca.DeviceScene(s)

@@ -229,7 +229,7 @@ def test_bad_arguments_fail_loudly(gpu):
         ds.render(rows=(3, 20, 8, 0, 2))  # row_begin not block-aligned with n_parts > 1
 
 
-def _random_scene(seed, w=72, h=48, opaque_mesh=False):
+def _random_scene(seed, w=72, h=48, opaque_mesh=False, extra_planes=False):
     """Seeded random scene mixing every primitive, light and material feature (incl. reflect +
     transparency on the same material, coincident planes, a mesh and stand-alone triangles)."""
     import json
@@ -254,6 +254,20 @@ def _random_scene(seed, w=72, h=48, opaque_mesh=False):
     if rng.rand() < 0.5:
         objs.append(dict(floor, material=int(rng.randint(nm))))  # coincident plane: exact tie on t
     objs.append({"type": "plane", "point": [0, 0, -3], "normal": [0, 0, 1], "material": int(rng.randint(nm))})
+    if extra_planes:
+        # more walls, axis-aligned (zeros of either sign, any length of normal) and not, anywhere in the object list
+        rng2 = np.random.RandomState(seed + 7919)
+        for _ in range(int(rng2.randint(1, 7))):
+            if rng2.rand() < 0.7:
+                a = int(rng2.randint(3))
+                n = [float(rng2.choice([0.0, -0.0])) for _ in range(3)]
+                n[a] = float(rng2.choice([-1.0, 1.0]) * rng2.choice([1.0, 0.25, 3.0, 1e-3]))
+                pt = [float(x) for x in rng2.uniform(-1, 1, 3)]
+                pt[a] = float(-np.sign(n[a]) * rng2.uniform(2.0, 6.0))
+            else:
+                n = [float(x) for x in rng2.uniform(-1, 1, 3)]
+                pt = [float(-4.0 * x) for x in n]
+            objs.insert(int(rng2.randint(len(objs) + 1)), {"type": "plane", "point": pt, "normal": n, "material": int(rng2.randint(nm))})
     if opaque_mesh or rng.rand() < 0.7:
         objs.insert(int(rng.randint(len(objs) + 1)), {"type": "mesh", "file": "scene/skull.stl", "material": int(rng.randint(nm))})
     lights = [{"type": "sun", "direction": v(-1, 1), "color": v(0.2, 1)}]
