@@ -76,6 +76,30 @@ def ref_cudaminmax_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hi
     return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)
 
 
+_ref_fmad = None
+
+
+def ref_fmad_lib():
+    """DIAGNOSTIC flavour: fminf/fmaxf semantics AND contraction of a*b+c into fused multiply-adds allowed (g++ -ffp-contract=fast
+    -mfma) — the kind of difference nvcc's default --fmad=true makes.  None when not built.  Never the parity target."""
+    global _ref_fmad
+    if _ref_fmad is None:
+        path = os.path.join(HERE, "_ref", "libcutrace_ref_fmad.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        _render_sig(L.ref_render)
+        _ref_fmad = L
+    return _ref_fmad
+
+
+def ref_fmad_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True):
+    L = ref_fmad_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libcutrace_ref_fmad.so not built (needs /root/reference)")
+    return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)
+
+
 def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids, want_uv=False):
     w, h = scene.size
     r = make_rows(h, rows)

@@ -196,6 +196,24 @@ def test_cuda_minmax_semantics_gap(ca):
         assert a["ray_count"] == c["ray_count"]
 
 
+def test_fma_contraction_gap_is_small_but_not_zero(ca):
+    """DIAGNOSTIC: the reference headers compiled with contraction allowed (what nvcc's default
+    --fmad=true does in its own way) against the parity target.  Most pixels change in some bit, nearly none by more than
+    the 1e-4 colour bar: a CUDA binary cannot be matched bit for bit by ANY host definition, and the bar holds away from
+    silhouettes.  scripts/cuda_fmad_gap.py reports the larger sizes (profiles/r03/cuda_fmad_gap.txt)."""
+    if oracle.ref_lib() is None or oracle.ref_fmad_lib() is None:
+        pytest.skip("oracle/_ref flavours not built here (need /root/reference)")
+    for name, w, h, b in (("bunny", 96, 54, 5), ("mirror", 96, 54, 8)):
+        s = load_scene(ca, name, w, h)
+        a = oracle.ref_render(s, bounces=b, threads=4)
+        c = oracle.ref_fmad_render(s, bounces=b, threads=4)
+        assert not same_bits(a["color"], c["color"]), name          # the flavour really contracts
+        assert np.abs(a["color"].astype(np.float64) - c["color"]).max() < 1e-4, name
+        fin = np.isfinite(a["depth"])
+        assert (np.isfinite(c["depth"]) == fin).all()
+        assert np.abs(a["depth"][fin].astype(np.float64) - c["depth"][fin]).max() < 1e-4
+
+
 UV_FIXTURES = [("triangle", 20, 20), ("sphere_plane", 96, 54), ("bunny", 96, 54)]
 
 
