@@ -641,7 +641,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         gn.resize(4 * tris.size());
         for (uint32_t k = 0; k < n; k++) {
           const ctr_triangle &t = src[order[k]];
-          make_tri(t.p1, t.p2, t.p3, order[k], tris[O.tri_begin + k], &gn[4 * (O.tri_begin + k)]);
+          make_tri(t.p1, t.p2, t.p3, order[k], tris[O.tri_begin + k], &gn[4 * (O.tri_begin + order[k])]);  // normals in FILE order: the kernel keeps only the winner's original index
         }
         for (uint32_t k = 0; n && k < CTR_GUARD_SLOTS; k++) {  // unused guard records: copies of the first triangle
           tris[O.tri_begin + n + k] = tris[O.tri_begin];

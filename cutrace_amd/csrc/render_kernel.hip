@@ -866,7 +866,6 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           // ---- mesh::intersect, default_schema.hpp:125-144: smallest valid t, FIRST triangle in
           //      file order on ties (strict < over file order)  ==  lexicographic min of (t, orig) ----
           float mt = INFINITY;
-          int mk_ = -1;
           uint32_t morig = 0xFFFFFFFFu;
           const bool anyhit_now = ANYHIT && shadow_cast;
           const mask_t anyhit_m = ANYHIT ? BALLOT(shadow_cast) : 0ull;
@@ -957,8 +956,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                   const mask_t occ_m = c_m & in_m & tin_m & ~flat_m & anyhit_m;
                   if (occ_m != 0ull) {
                     CTR_MARK(26);
-                    if (INVB(occ_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }  // the handler only asks best < light_dist
-                    bb_m &= ~occ_m;
+                    bb_m &= ~occ_m;  // (retired: best / bobj are set once, where the mesh is left)
                     c_m &= ~occ_m;
                   }
                 }
@@ -1009,10 +1007,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                   // within et of the light distance.
                   if (!exact_t && !(tq + et < light_dist) && !(tq - et >= light_dist)) { CTR_MARK(122); t0 = A0 / alpha; }
                   CTR_MARK(123);
-                  if (t0 > min_t && t0 < light_dist) {
-                    best = t0; bobj = (int)i;   // any value < light_dist: the handler only compares
-                    retire = true;
-                  }
+                  if (t0 > min_t && t0 < light_dist) retire = true;  // (best / bobj: where the mesh is left)
                 } else {
                   CTR_MARK(124);
                   // the exact value of t0 matters only if it can beat or tie the nearest hit so far
@@ -1020,7 +1015,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                   CTR_MARK(126);
                   const uint32_t orig = T.orig;
                   if (exact_t && (t0 < mt || (t0 == mt && orig < morig))) {
-                    mt = t0; mk_ = (int)tri_index; morig = orig;
+                    mt = t0; morig = orig;
                     lim = fminf(lim, mt);
                   }
                 }
@@ -1102,7 +1097,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               // launch -5 %; a 1 000-triangle mesh, which stays in the scalar cache anyway, +-0.5 %
               // (profiles/r03/exp_leaf_touch.txt).  The wait is part of the statement, so the unread register is dead when it
               // ends.  (ctr_api.cpp allocates 256 bytes beyond every array for requests past the last triangle.)
-              if (n_l == 0u) return;
+              // (no early exit for an empty leaf — the unused slots of a node, whose far-away point box no ray enters: it
+              //  would only re-test the mesh's first triangle, which changes nothing, and the extra edge costs six register
+              //  copies per leaf visit in the compiler's output)
               typedef uint32_t u32x16_ __attribute__((ext_vector_type(16)));
               u32x16_ t0;
               uint32_t touch_;
@@ -1210,10 +1207,17 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             st[10] += (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_tris);
           }
           CTR_MARK(35);  // mesh left
-          if (ANYHIT) live = live && !INVB(bb0_m & ~bb_m);  // lanes retired inside the mesh
+          if (ANYHIT) {
+            // lanes retired inside the mesh (deciding shadow rays that met an occluder): the handler only asks
+            // best < light_dist.  Written here, once, rather than in the triangle test: values a loop changes are copied
+            // in and out of it by the compiler (six v_mov each way per leaf visit for six such values; now three).
+            const bool retired = INVB(bb0_m & ~bb_m);
+            if (retired) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }
+            live = live && !retired;
+          }
           ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
           cand = mt;
-          ctri = mk_;
+          ctri = (int)(beg + morig);  // gnorm is indexed by the triangle's FILE-order position within its mesh
 #ifdef CTR_TIMING
           {
             const unsigned long long t_mesh1 = __builtin_readcyclecounter();

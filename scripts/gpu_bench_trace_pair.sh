@@ -9,6 +9,7 @@ python3 -c "
 import json
 b=json.loads(open('gpurun_out/bench_pair.json').read().strip().splitlines()[-1])
 print(b['value'], b['ms_per_step'], b['roofline']['kernel_ms_avg'], b['roofline']['clock_ghz_this_run'], b['roofline']['frac'])
-b=json.loads(open('gpurun_out/prof_pair.log').read().strip().splitlines()[-1])
-print('under rocprof:', b['value'], b['ms_per_step'], b['roofline']['kernel_ms_avg'], b['roofline']['clock_ghz_this_run'])
+for l in open('gpurun_out/prof_pair.log'):
+    if l.startswith('{\"metric\"'):
+        b=json.loads(l); print('under rocprof:', b['value'], b['ms_per_step'], b['roofline']['kernel_ms_avg'], b['roofline'].get('clock_ghz_this_run'))
 "
