@@ -74,7 +74,7 @@
 #define PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))  /* opaque to LICM / speculation */
 #define INVB(m) __builtin_amdgcn_inverse_ballot_w64(m)   /* wave-uniform lane mask -> per-lane predicate */
 #define FCMP(a, b, pred) __builtin_amdgcn_fcmpf((a), (b), (pred))  /* v_cmp straight into a lane mask */
-enum { FC_OGT = 2, FC_OGE = 3, FC_OLT = 4, FC_OLE = 5 };          /* LLVM FCmp predicate numbers */
+enum { FC_OEQ = 1, FC_OGT = 2, FC_OGE = 3, FC_OLT = 4, FC_OLE = 5 };  /* LLVM FCmp predicate numbers */
 #define TL_NONE 0x7FFFFFFFu                                        /* "no more top-level items" */
 
 // v_writelane_b32 with a wave-uniform value and lane select: this clang has no __builtin for it, so the
@@ -494,17 +494,21 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     const bool k_has_mesh = hot[7] != 0u;
     TSTAMP(t_trip0);
     CTR_MARK(1);  // trip head: cast set-up
+    typedef unsigned long long mask_t;
     const bool active = MSP_ACTIVE(msp);
     const bool shadow_cast = MSP_IS_SHADOW(msp);
-    n_casts += (unsigned long long)__builtin_popcountll(BALLOT(active));
-    if (STATS) { st[0]++; st[5] += __builtin_popcountll(BALLOT(active)); }
+    const mask_t active_m = BALLOT(active);
+    n_casts += (unsigned long long)__builtin_popcountll(active_m);
+    if (STATS) { st[0]++; st[5] += __builtin_popcountll(active_m); }
 
     // =====================================================================
     // ray_cast (ray_cast.hpp:29-55): nearest hit of (ro, rd) over all objects
     // =====================================================================
     float best = INFINITY;
     int bobj = -1, btri = -1;
-    bool live = active;  // lanes still searching (any-hit mode retires occluded lanes)
+    // lanes still searching (any-hit mode retires occluded lanes), as a lane MASK: a per-lane bool that crosses blocks
+    // is kept as a mask by the compiler anyway, and every BALLOT of it costs two vector instructions to get it back
+    mask_t alive_m = active_m;
     V3 rinv = mk(0, 0, 0);     // exact 1/dir (IEEE divisions), computed lazily: see the mesh branch
     bool have_rinv = false;    // wave-uniform
     V3 ria = mk(0, 0, 0);
@@ -524,11 +528,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     TSTAMP(t_loop0);
     TACC(0, t_trip0, t_loop0);
     CTR_MARK(3);  // planes: set-up
-    typedef unsigned long long mask_t;
     const bool anyhit_cast = ANYHIT && shadow_cast;
     // ---- planes: plane::intersect, default_schema.hpp:189-201, all in lane masks ----
     {
-      mask_t live_m = BALLOT(live);
+      mask_t live_m = alive_m;
       // t0 = num/den is an IEEE division, and it is only worth doing where the quotient can matter.
       // Classification WITHOUT dividing (and without a reciprocal): with num' = num * sign(den) and
       // den' = |den| the quotient is num'/den', so
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         CTR_MARK(4);
         // NaN iff some component is not finite (or the sum overflows: then the general code, which is always right)
         const float chk = (((((ro.x + ro.y) + ro.z) + rd.x) + rd.y) + rd.z) * 0.0f;
-        axis_fast = BALLOT(live && !(chk == 0.0f)) == 0ull;
+        axis_fast = (alive_m & ~FCMP(chk, 0.0f, FC_OEQ)) == 0ull;
       }
       for (uint32_t p = 0; p < n_recs;) {
         if (n_recs - p >= 3u) {
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           }
         }
       }
-      if (ANYHIT) live = INVB(live_m);
+      if (ANYHIT) alive_m = live_m;
     }
     TSTAMP(t_planes1);
     TACC(1, t_loop0, t_planes1);
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     bool sph_have = false;  // wave-uniform
     for (uint32_t oi = 0; oi < k_n_oloop; ++oi) {
       if (ANYHIT) {
-        if (BALLOT(live) == 0ull) break;
+        if (alive_m == 0ull) break;
       }
       const CADDR DObj &O = AK->oloop[oi];
       const uint32_t i = O.index;
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         // sub < 0: sqrt gives NaN, both roots are NaN, the sphere is missed (that IS how the reference
         // signals a miss) — so the square root and the two divisions run only if some live lane has
         // sub >= 0 or NaN (the exact reference value of sub decides, no margin involved)
-        if (BALLOT(live && !(sub < 0.0f)) != 0ull) {
+        if ((alive_m & ~FCMP(sub, 0.0f, FC_OLT)) != 0ull) {
           CTR_MARK(11);  // sphere roots
           const float sq = sqrtf(sub);
           const float t0 = (dec - sq) / dd, t1 = (dec + sq) / dd;
@@ -705,14 +708,12 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       }
       CTR_MARK(12);  // object loop: candidate merge
       // ray_cast.hpp:43 — strict <, first object in scene order wins ties
-      if (live && ok && cand > min_t && (cand < best || (cand == best && (int)i < bobj))) {
+      if (INVB(alive_m) && ok && cand > min_t && (cand < best || (cand == best && (int)i < bobj))) {
         best = cand;
         bobj = (int)i;
         btri = ctri;
       }
-      if (ANYHIT) {
-        if (shadow_cast && live && ok && cand > min_t && cand < light_dist) live = false;
-      }
+      if (ANYHIT) alive_m &= ~BALLOT(shadow_cast && ok && cand > min_t && cand < light_dist);
     }
     // ---- meshes, reached through a top-level BVH over their boxes (bvh.h layout, one mesh per leaf)
     //      so that a cast only looks at meshes some lane's ray can touch.  Visiting order does not
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       for (;;) {
         TSTAMP(t_tl0);
         if (ANYHIT) {
-          if (BALLOT(live) == 0ull) break;
+          if (alive_m == 0ull) break;
         }
         // (nothing left: TL_NONE has no leaf flag, and without this test a scene's LAST mesh was followed by one more
         //  descent set-up — ~30 vector instructions per cast for nothing, found by the execution profile, scripts/dynamic_mix.py)
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         // descend the top-level tree to the next mesh leaf
         if (!(t_pend & BVH_LEAF_FLAG)) {
           CTR_MARK(14);  // top-level descent set-up
-          const mask_t lv_m = BALLOT(live);
+          const mask_t lv_m = alive_m;
           const float t_lim = anyhit_cast ? light_dist : best;
           // conservative box test constants, as in the per-mesh walk below (world-space margin
           // 2^-14 x G); recomputed per descent so that nothing stays live across the mesh code
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         {
           // Everything in this branch works on 64-bit lane masks (v_cmp results kept in SGPRs and
           // combined on the scalar unit) instead of per-lane booleans.
-          const mask_t live_m = BALLOT(live);
+          const mask_t live_m = alive_m;
           // ---- mesh::bound_intersects, default_schema.hpp:99-114 ----
           // The reference's slab test needs three IEEE divisions (1/dir) per ray.  With 1-ulp
           // reciprocals every t is within 3 ulp of the exact one and tmin/tmax are 1-Lipschitz in
@@ -1211,9 +1212,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             // lanes retired inside the mesh (deciding shadow rays that met an occluder): the handler only asks
             // best < light_dist.  Written here, once, rather than in the triangle test: values a loop changes are copied
             // in and out of it by the compiler (six v_mov each way per leaf visit for six such values; now three).
-            const bool retired = INVB(bb0_m & ~bb_m);
-            if (retired) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }
-            live = live && !retired;
+            const mask_t retired_m = bb0_m & ~bb_m;
+            if (INVB(retired_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }
+            alive_m &= ~retired_m;
           }
           ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
           cand = mt;
@@ -1229,14 +1230,13 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 
         }
         // ray_cast.hpp:43 — strict <, first object in scene order wins ties
-        if (live && ok && cand > min_t && (cand < best || (cand == best && (int)i < bobj))) {
+        if (INVB(alive_m) && ok && cand > min_t && (cand < best || (cand == best && (int)i < bobj))) {
           best = cand;
           bobj = (int)i;
           btri = ctri;
         }
-        if (ANYHIT) {
-          if (shadow_cast && live && ok && cand > min_t && cand < light_dist) live = false;
-        }
+        // (no "a deciding shadow ray with a valid mesh hit stops searching" here: in the any-hit build such a lane never
+        //  records a mesh hit — it retires inside the walk, above)
       }
     }
     const bool was_hit = bobj >= 0;
