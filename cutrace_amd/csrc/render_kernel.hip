@@ -858,7 +858,6 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           TACC(3, t_tl0, t_bb);
           CTR_MARK(21);
           if (bb_m == 0ull) continue;  // no lane of this wave needs the mesh
-          const mask_t bb0_m = bb_m;
           CTR_MARK(22);  // mesh entered: walk set-up
           const uint32_t beg = o_tri_begin, cnt = o_tri_count;
           if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
@@ -958,6 +957,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                   if (occ_m != 0ull) {
                     CTR_MARK(26);
                     bb_m &= ~occ_m;  // (retired: best / bobj are set once, where the mesh is left)
+                    alive_m &= ~occ_m;
                     c_m &= ~occ_m;
                   }
                 }
@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             if (ANYHIT) {
               const mask_t rm = BALLOT(retire);
               bb_m &= ~rm;
+              alive_m &= ~rm;
             }
           };
 
@@ -1212,9 +1213,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             // lanes retired inside the mesh (deciding shadow rays that met an occluder): the handler only asks
             // best < light_dist.  Written here, once, rather than in the triangle test: values a loop changes are copied
             // in and out of it by the compiler (six v_mov each way per leaf visit for six such values; now three).
-            const mask_t retired_m = bb0_m & ~bb_m;
-            if (INVB(retired_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }
-            alive_m &= ~retired_m;
+            // (every deciding shadow ray that has retired by now, in this mesh or before it: writing the same again for the
+            //  earlier ones is harmless — the handler never asks which object it was — and saves carrying the mesh's entry
+            //  mask through the walk: scalar registers are what this kernel is shortest of)
+            if (INVB(anyhit_m & ~alive_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }
           }
           ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
           cand = mt;
