@@ -309,6 +309,17 @@ struct KArgs {
 static_assert(offsetof(KArgs, planes) == 0 && offsetof(KArgs, has_mesh) == 28, "KArgs: the hot block is the first eight dwords");
 static_assert(offsetof(KArgs, objs) == 32 && offsetof(KArgs, mats) == 56 && offsetof(KArgs, bounces) == 68, "KArgs: the cold block follows");
 
+// The kernel's whole argument block as it lies in the kernarg segment: the output pointers are read from there where a
+// pixel is written (the first cast's depth and normal, the colour when the pixel is finished) instead of living in
+// eight SGPRs across every cast — where the compiler parked them in VGPR lanes and fetched them back after each cast's
+// mesh walk (eight v_readlane per cast for pointers two casts in thirty use).
+struct KParams {
+  KArgs A;
+  float *depth_out, *color_out, *normal_out;
+  unsigned long long *counters;
+};
+static_assert(sizeof(KArgs) % 8 == 0 && offsetof(KParams, depth_out) == sizeof(KArgs), "KParams mirrors the kernel's parameter list");
+
 // ---- Host delivery ----
 // ctr_render hands the kernel page-locked HOST buffers.  Storing the pixels there tile by tile works (the memory is
 // device-visible) but reaches PCIe as 32- and 96-byte runs: 43 GB/s for the stores alone, where one DMA of the frame
@@ -375,7 +386,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   CTR_MARK(0);  // wave prologue
   const uint32_t w = A.w, h = A.h;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform by construction
+  // wave-uniform by construction; with one wave per workgroup (the shipped build) a compile-time zero, so that no LDS base
+  // offset derived from it has to be carried (parked in a VGPR lane and fetched back every cast) through the kernel
+  const uint32_t wave_in_wg = WAVES_PER_WG == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t slot = (blockIdx.x * WAVES_PER_WG) + wave_in_wg;
   const uint32_t tiles_x = (w + TW - 1) / TW;
   const uint32_t tiles_y = (A.rows.n_rows + TH - 1) / TH;
@@ -1330,9 +1343,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         // kernel.hpp:55-56 (depth = +inf, normal = 0 on a miss)
         CTR_MARK(40);
         const size_t px_id = px_index();
-        if (HOSTOUT) __hip_atomic_store(depth_out + px_id, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else depth_out[px_id] = best;
-        store3(normal_out, px_id, normal);
+        float *const k_depth_out = ((const CADDR KParams *)AK)->depth_out, *const k_normal_out = ((const CADDR KParams *)AK)->normal_out;
+        if (HOSTOUT) __hip_atomic_store(k_depth_out + px_id, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else k_depth_out[px_id] = best;
+        store3(k_normal_out, px_id, normal);
         if (UV) {
           float *const uvp = AK->uv_out;
           uvp[2 * px_id + 0] = tc_u;
@@ -1480,7 +1494,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         CTR_MARK(52);  // unwind one level
         if (sp == 0) {
           const size_t px_id = px_index();
-          store3(color_out, px_id, out_rgb);
+          store3(((const CADDR KParams *)AK)->color_out, px_id, out_rgb);
           msp = MSP_DONE;
           break;
         }
