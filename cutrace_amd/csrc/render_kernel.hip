@@ -511,6 +511,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     const bool active = MSP_ACTIVE(msp);
     const bool shadow_cast = MSP_IS_SHADOW(msp);
     const mask_t active_m = BALLOT(active);
+    const mask_t shadow_m = BALLOT(shadow_cast);  // (taken here, straight from the compare: see alive_m below)
     n_casts += (unsigned long long)__builtin_popcountll(active_m);
     if (STATS) { st[0]++; st[5] += __builtin_popcountll(active_m); }
 
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.x), t_lead) >> 31) |
                (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.y), t_lead) >> 31) << 1) |
                (((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(rd.z), t_lead) >> 31) << 2)) ^
-              ((ANYHIT && ((uint32_t)__builtin_amdgcn_readlane((int)msp, t_lead) >> 31) != 0u) ? 7u : 0u);
+              ((ANYHIT && ((shadow_m >> t_lead) & 1ull) != 0ull) ? 7u : 0u);
           while (t_pend != TL_NONE && !(t_pend & BVH_LEAF_FLAG)) {
             const CADDR DNode &N = A.nodes[AK->tlas_begin + t_pend];
             CTR_MARK(15);  // top-level node
@@ -782,17 +783,20 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             //  the one it wants after the test — a second dependent round trip per node)
             uint32_t n_left = N.left, n_right = N.right;
             asm volatile("" : "+s"(n_left), "+s"(n_right));
-            const bool h0 = t_hits(0) != 0ull, h1 = t_hits(1) != 0ull;
-            const bool hl = t_rev ? h1 : h0, hr = t_rev ? h0 : h1;
+            // (which children are hit as two bits of a scalar integer: as `bool`s picked by another bool the compiler sends
+            //  them through a VGPR and back — two v_cndmask and two v_readfirstlane per node)
+            const uint32_t c0 = (uint32_t)__builtin_popcountll(t_hits(0)), c1 = (uint32_t)__builtin_popcountll(t_hits(1));
+            const uint32_t hit01 = (c0 < 1u ? c0 : 1u) | ((c1 < 1u ? c1 : 1u) << 1);  // (umin: no boolean anywhere)
+            const uint32_t hit = t_rev ? (((hit01 & 1u) << 1) | (hit01 >> 1)) : hit01;  // bit 0: the nearer child, bit 1: the farther
             const uint32_t dl = t_rev ? n_right : n_left, dr = t_rev ? n_left : n_right;
-            if (hl && hr) {
+            if (hit == 3u) {
               t_stack_v = ctr_writelane(__builtin_amdgcn_readfirstlane(dr),
                                                        __builtin_amdgcn_readfirstlane(t_sp), t_stack_v);
               t_sp++;
               t_pend = dl;
-            } else if (hl) {
+            } else if (hit == 1u) {
               t_pend = dl;
-            } else if (hr) {
+            } else if (hit == 2u) {
               t_pend = dr;
             } else if (t_sp != 0u) {
               t_sp--;
@@ -881,7 +885,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           float mt = INFINITY;
           uint32_t morig = 0xFFFFFFFFu;
           const bool anyhit_now = ANYHIT && shadow_cast;
-          const mask_t anyhit_m = ANYHIT ? BALLOT(shadow_cast) : 0ull;
+          const mask_t anyhit_m = ANYHIT ? shadow_m : 0ull;
           const bool t_filter = A.fudge >= 1e-30f;  // then min_t > 0 in every cast (wave-uniform)
           // no triangle/node beyond `lim` can matter: the light for a deciding shadow ray, else the
           // nearest hit so far (other objects, then this mesh)
@@ -1078,7 +1082,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             // 64 000-triangle mesh -8 % against near-to-far for both; profiles/r02/traversal_order.txt).
             // (only where a shadow cast stops at its first occluder; the ordered shadow loop of scenes with transparent
             //  materials is a nearest-hit cast)
-            const uint32_t lead_shadow = (ANYHIT && ((uint32_t)__builtin_amdgcn_readlane((int)msp, lead) >> 31) != 0u) ? 7u : 0u;
+            const uint32_t lead_shadow = (ANYHIT && ((shadow_m >> lead) & 1ull) != 0ull) ? 7u : 0u;
             const uint32_t neg_bits = lead_shadow ^ (nb_x | (nb_y << 1) | (nb_z << 2));
             // the nine per-ray constants of the box test, two to a register pair; PKFMA picks the half it
             // needs with op_sel, so packing costs no extra registers
