@@ -772,9 +772,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               const float t1x = __builtin_fmaf(N.mn[0][c], ria.x, -t_ka.x), t2x = __builtin_fmaf(N.mx[0][c], ria.x, -t_kb.x);
               const float t1y = __builtin_fmaf(N.mn[1][c], ria.y, -t_ka.y), t2y = __builtin_fmaf(N.mx[1][c], ria.y, -t_kb.y);
               const float t1z = __builtin_fmaf(N.mn[2][c], ria.z, -t_ka.z), t2z = __builtin_fmaf(N.mx[2][c], ria.z, -t_kb.z);
-              const float lo = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-              const float hi = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-              return lv_m & ~(FCMP(lo, hi, FC_OGT) | FCMP(hi, min_t, FC_OLT) | FCMP(lo, t_lim, FC_OGT));
+              // as in the per-mesh walk: a lane takes the child unless max(entry, min_t) > min(exit, limit) for certain
+              // (v_min / v_max drop a NaN operand: that axis' constraint drops out; one compare instead of three)
+              const float lo = slab_lo4(t1x, t2x, t1y, t2y, t1z, t2z, min_t);
+              const float hi = slab_hi4(t1x, t2x, t1y, t2y, t1z, t2z, t_lim);
+              return lv_m & ~FCMP(lo, hi, FC_OGT);
             };
             // visiting order as in the per-mesh walk (speed only): along the lead ray for nearest-hit casts, against
             // it for any-hit shadow casts
