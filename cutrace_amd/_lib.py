@@ -90,7 +90,7 @@ _hip = None
 def host_lib():
     global _host
     if _host is None:
-        path = os.path.join(PKG, "libcutrace_host.so")
+        path = os.environ.get("CUTRACE_HOST_LIB") or os.path.join(PKG, "libcutrace_host.so")  # override: sanitizer builds (scripts/cpu_sanitize.sh)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `python -m cutrace_amd.build` (or __graft_entry__.build())")
         L = C.CDLL(path)

@@ -21,7 +21,7 @@ def _render_sig(fn, uv=False):
 def oracle_lib():
     global _oracle
     if _oracle is None:
-        path = os.path.join(HERE, "libctr_oracle.so")
+        path = os.environ.get("CUTRACE_ORACLE_LIB") or os.path.join(HERE, "libctr_oracle.so")  # override: sanitizer builds
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `make -C oracle oracle`")
         L = C.CDLL(path)
