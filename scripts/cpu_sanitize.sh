@@ -13,3 +13,6 @@ export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export CUTRACE_HOST_LIB=$OUT/libcutrace_host_san.so CUTRACE_ORACLE_LIB=$OUT/libctr_oracle_san.so
 python -m pytest tests/test_loader.py tests/test_oracle_golden.py -x -q -m "not gpu" -p no:cacheprovider
 python scripts/cpu_fuzz_loader.py 3000
+# the BVH builders (host half of the GPU library that needs no device) on random and degenerate inputs
+g++ -std=c++17 -O1 $SAN -Icutrace_amd/csrc -Iinclude -o $OUT/bvh_check scripts/bvh_check.cpp cutrace_amd/csrc/bvh.cpp
+env -u LD_PRELOAD $OUT/bvh_check
