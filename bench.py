@@ -167,6 +167,15 @@ def campath(ca, hs, device):
     return res
 
 
+def _live_summary(st):
+    """ctr_debug_lane_stats, condensed for the bench line: the live fraction over all trips (= lane_usefulness.cast), the
+    trips by number of live lanes, and per kind of cast the mean number of live lanes in the trips that have any."""
+    return {"cast": st["live_fraction"], "wave_trips": st["wave_trips"],
+            "trips_by_live_lanes_1_8_to_57_64": st["trips_by_live_lanes_1_8_to_57_64"],
+            "mean_live_lanes_by_kind": {k: round(v["lanes_per_trip"], 1) for k, v in st["by_kind"].items()},
+            "trips_a_perfect_repacking_would_save": 1.0 - (st["live_fraction"] or 0.0)}
+
+
 def extras(ca, hs, args, ds):
     """Untimed side measurements reported in `config` (never part of `value`)."""
     import statistics
@@ -230,7 +239,7 @@ def extras(ca, hs, args, ds):
     #      other single-GPU configs too — what a one-frame-per-process `cutrace <scene.json>` pays
     if os.path.basename(args.scene) == "bunny.json":
         d = tempfile.mkdtemp()
-        fl = {}
+        fl, live = {}, {}
         for name, path, b in (("C1 sphere_plane.json", os.path.join(ROOT, "scene", "sphere_plane.json"), 5),
                               ("C3 mirror.json b8", os.path.join(ROOT, "scene", "mirror.json"), 8),
                               ("C3-deep (walls reflect 0.5) b8", scenes.make_mirror_deep(d), 8)):
@@ -242,8 +251,15 @@ def extras(ca, hs, args, ds):
                 x.render(bounces=b)
             steady = statistics.median(x.render(bounces=b)["kernel_ms"] for _ in range(7))
             fl[name] = {"first_launch_kernel_ms": first, "steady_kernel_ms": steady}
+            # how many of a wave's 64 lanes are alive per trip on this config: one lane = one pixel for
+            # the pixel's whole life, so lanes whose recursion ends early idle (shading.hpp:126-150)
+            x.set_variant(ca.VAR_STATS)
+            ca.DeviceScene.lane_stats(reset=True)
+            x.render(bounces=b)
+            live[name] = _live_summary(ca.DeviceScene.lane_stats(reset=True))
             x.close()
         out["first_launch_by_config"] = fl
+        out["live_lanes_by_config"] = live
         # (3c) a MOVING camera (90 frames, eye ~1.5 cm and view ~0.35 deg per frame): every frame is ordered by the costs
         #      of the previous, different frame — against image order (scripts/gpu_campath.py's loop)
         out.update(campath(ca, hs, ds.device))
@@ -332,8 +348,31 @@ def roofline_from_profiles(workload, kern_avg_ms, counters_json):
     return roof
 
 
+def self_launch(args):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks ourselves, as
+    a CHILD process — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same
+    arguments>` — wait for it, and exit with its code.  This runs before `import torch` and before anything touches a
+    device (never replace a process that has initialised the GPU); the child inherits stdout / stderr, so rank 0's ONE
+    JSON line is this command's line."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this image
+    env["CUTRACE_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
     import cutrace_amd as ca
@@ -343,8 +382,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        if world == 1 and args.gpus > 1:   # (RANK / WORLD_SIZE=1 set by hand: self_launch() above covers the plain command)
+            raise SystemExit("bench.py --gpus %d: WORLD_SIZE=1 in the environment; unset RANK / WORLD_SIZE or use "
+                             "torch.distributed.run" % args.gpus)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     # Rehearsal on a one-GPU box (never the measured configuration): CUTRACE_BENCH_SHARE_GPU=1 puts every
@@ -360,6 +400,21 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # what the process group itself says it is (the record shows RCCL saw N ranks on N distinct devices)
+    dist_info = {"world_size": 1, "backend": None, "launched_by": "single process", "devices": [local_rank]}
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        every = torch.zeros(world, 5, dtype=torch.int64, device=dev)   # (a SUM of one-hot rows: gloo has no GPU all_gather)
+        every[rank] = torch.tensor([rank, local_rank, torch.cuda.current_device(), int(getattr(props, "pci_bus_id", -1)),
+                                    int(getattr(props, "pci_domain_id", -1))], dtype=torch.int64, device=dev)
+        dist.all_reduce(every)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "launched_by": "bench.py itself (child torch.distributed.run)" if os.environ.get("CUTRACE_BENCH_SELF_LAUNCHED") == "1"
+                                    else "external launcher",
+                     "devices": [int(t[2]) for t in every],
+                     "ranks": [{"rank": int(t[0]), "local_rank": int(t[1]), "cuda_device": int(t[2]), "pci_bus_id": int(t[3]),
+                                "pci_domain_id": int(t[4])} for t in every],
+                     "shared_gpu_rehearsal": os.environ.get("CUTRACE_BENCH_SHARE_GPU") == "1"}
 
     if args.workload == "c4":
         import tempfile
@@ -497,6 +552,13 @@ def main():
                               "over %d GPU(s), gathered to rank 0" % (args.bounces, world),
                   "n_gpus": world, "steps": 6, "frame_ms": c4_dt / 6 * 1e3, "mrays_per_s": c4_rays * 6 / c4_dt / 1e6,
                   "rays_per_frame": c4_rays, "kernel_ms_avg_over_ranks": c4_kern}
+        if world == 1:
+            c4_ds = ca.DeviceScene(c4_hs, device=local_rank)
+            c4_ds.set_variant(ca.VAR_STATS)
+            ca.DeviceScene.lane_stats(reset=True)
+            c4_ds.render(bounces=args.bounces)
+            c4_leg["live_lanes"] = _live_summary(ca.DeviceScene.lane_stats(reset=True))
+            c4_ds.close()
         del c4_tiler
     if rank == 0:
         total_rays = rays_step * args.steps
@@ -512,6 +574,7 @@ def main():
                   "tile_order": "expensive tiles first, costs recorded by the previous launch of the same "
                                 "shape (first launch of a shape: blocks of tiles from the image centre outwards)",
                   "kernel_ms_image_order": kern_io,
+                  "dist": dist_info,
                   "frames_per_step": frames, "rays_per_step": rays_step,
                   "frame_ms": dt_max / args.steps * 1e3 / frames,
                   "unique_mrays_per_s": (rays_step - frames * w * h) * args.steps / dt_max / 1e6}

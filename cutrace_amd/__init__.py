@@ -248,6 +248,28 @@ class DeviceScene:
         _lib.hip_lib().ctr_last_counters(self._h, out.ctypes.data)
         return out
 
+    @staticmethod
+    def lane_stats(reset=True):
+        """Live-lane statistics of the VAR_STATS launches since the last reset (ctr_debug_lane_stats), decoded."""
+        raw = np.zeros(80, np.uint64)
+        if _lib.hip_lib().ctr_debug_lane_stats(raw.ctypes.data, 1 if reset else 0):
+            raise RuntimeError("ctr_debug_lane_stats failed")
+        c = [int(x) for x in raw]
+        trips, live = c[72], c[73]
+        out = {"wave_trips": trips, "live_lanes_per_trip": live / trips if trips else None,
+               "live_fraction": live / (64.0 * trips) if trips else None,
+               "live_fraction_of_in_image_lanes": (live / trips) / (c[75] / c[74]) if trips and c[74] and c[75] else None,
+               "trips_by_live_lanes_1_8_to_57_64": c[64:72], "trips_mixing_kinds": c[76], "waves": c[74]}
+        kinds = {}
+        for d in range(16):
+            for name, base in (("radiance", 0), ("shadow", 16)):
+                if c[32 + base + d]:
+                    label = "primary" if (name == "radiance" and d == 0) else f"{name}@depth{d}"
+                    kinds[label] = {"lanes": c[base + d], "trips": c[32 + base + d],
+                                    "lanes_per_trip": c[base + d] / c[32 + base + d]}
+        out["by_kind"] = kinds
+        return out
+
     def tile_costs(self):
         """Per-tile cost of the last launch (ctr_tile_costs), as a uint32 array."""
         L = _lib.hip_lib()

@@ -77,7 +77,7 @@ HIP_SYMBOLS = [
     "ctr_scene_size", "ctr_scene_set_size", "ctr_render", "ctr_render_device", "ctr_set_variant",
     "ctr_scene_set_cameras", "ctr_render_device_batch",
     "ctr_algorithmic_bytes", "ctr_frame_alloc", "ctr_frame_free", "ctr_tile_costs", "ctr_last_counters", "ctr_selftest_exact_math",
-    "ctr_debug_poison_next_order", "ctr_render_uv",
+    "ctr_debug_poison_next_order", "ctr_render_uv", "ctr_debug_lane_stats",
     "ctr_multi_create", "ctr_multi_destroy", "ctr_multi_devices", "ctr_multi_transport", "ctr_multi_size", "ctr_multi_set_size",
     "ctr_multi_set_variant", "ctr_render_multi", "ctr_multi_kernel_ms", "ctr_reinterleave_device",
     "ctr_multi_submit", "ctr_multi_wait",
@@ -167,6 +167,7 @@ def hip_lib():
             "ctr_selftest_exact_math": ([C.POINTER(C.c_uint64)], C.c_int),
             "ctr_last_counters": ([C.c_void_p, C.c_void_p], C.c_int),
             "ctr_debug_poison_next_order": ([C.c_void_p], C.c_int),
+            "ctr_debug_lane_stats": ([C.c_void_p, C.c_int], C.c_int),
             "ctr_render_uv": ([C.c_void_p, C.c_float, C.c_int, C.POINTER(Rows), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(RenderStats)], C.c_int),
             "ctr_tile_costs": ([C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)], C.c_int),

@@ -421,7 +421,16 @@ int ctr_multi_submit(ctr_multi *m, float fudge, int bounces, uint64_t block_rows
   if (n == 1 && !m->use_rccl && (direct || !dest_pinned)) {
     // one device: ctr_render is the better path both for page-locked destinations (delivered by the kernel) and for
     // pageable ones (its three plain copies: 2.2 ms per 1080p frame where queuing them on a side stream took 4.8)
-    if ((st = ctr_render(P0.scene, fudge, bounces, nullptr, depth, color3, normal3, &F.one))) return st;
+    // An earlier frame may have taken the asynchronous path (a page-locked destination under CTR_VAR_NO_DIRECT) and still
+    // be running on P0's streams, which do not synchronise with the null stream ctr_render launches on: two launches on
+    // ONE scene handle would share its counter shards, cost table and dispatch order.  Drain it first; the
+    // frame stays queued (its events have fired by then, ctr_multi_wait returns it at once).
+    if (m->inflight) {
+      hipError_t e = hipStreamSynchronize(P0.stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(P0.cstream);
+      if (e != hipSuccess) return fail_sync(m, mfail(CTR_E_HIP_BASE + (int)e, std::string("ctr_multi_submit: ") + hipGetErrorString(e)));
+    }
+    if ((st = ctr_render(P0.scene, fudge, bounces, nullptr, depth, color3, normal3, &F.one))) return fail_sync(m, st);
     F.sync_done = true;
     F.busy = true;
     m->inflight++;

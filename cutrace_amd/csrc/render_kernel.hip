@@ -87,6 +87,19 @@ namespace {
 __device__ unsigned int g_prof[128];  // executions of the CTR_MARK segments, summed over the waves of every launch
 #endif
 
+// ---- how many lanes are alive (KV_STATS builds only; read by ctr_debug_lane_stats) ----
+// A lane is one pixel for the pixel's whole life, and every trip of the kernel's loop casts one ray for every lane that
+// still needs one — so lanes whose pixel is finished, or whose recursion is shallower than their neighbours', idle while
+// the wave goes on (shading.hpp:126-150 is what diverges).  Counted per trip, split by what the lane casts for and how
+// deep its recursion is:
+//   [0..15]  lanes casting a radiance ray at recursion depth d (d = 0: the primary ray), summed over the trips
+//   [16..31] lanes casting a shadow ray for a hit at depth d
+//   [32..47] trips in which at least one lane casts a radiance ray at depth d;   [48..63] the same for shadow rays
+//   [64..71] trips by the number of live lanes: 1-8, 9-16, ..., 57-64
+//   [72] trips, [73] live lanes summed over the trips, [74] waves, [75] lanes inside the image summed over the waves,
+//   [76] trips in which the live lanes cast for more than one (kind, depth)
+__device__ unsigned long long g_lane_stats[80];
+
 // ---- execution profile of the source's straight-line segments (scripts/dynamic_mix.py) ----
 // CTR_MARK(n) opens segment n.  -DCTR_MARKS: a comment in the ISA, from which the segment's instructions are counted;
 // -DCTR_PROFILE: a counter of how often a wave runs the segment — one global atomic add by lane 0 with EXEC forced
@@ -513,7 +526,28 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     const mask_t active_m = BALLOT(active);
     const mask_t shadow_m = BALLOT(shadow_cast);  // (taken here, straight from the compare: see alive_m below)
     n_casts += (unsigned long long)__builtin_popcountll(active_m);
-    if (STATS) { st[0]++; st[5] += __builtin_popcountll(active_m); }
+    if (STATS) {
+      st[0]++; st[5] += __builtin_popcountll(active_m);
+      uint32_t kinds = 0;
+      for (uint32_t d = 0; d < 16u; d++) {
+        const mask_t r_m = BALLOT(MSP_IS_RADIANCE(msp) && (uint32_t)MSP_DEPTH(msp) == d);
+        const mask_t s_m = BALLOT(shadow_cast && (uint32_t)MSP_DEPTH(msp) == d);
+        kinds += (r_m != 0ull) + (s_m != 0ull);
+        if (lane == 0) {
+          if (r_m) { atomicAdd(&g_lane_stats[d], (unsigned long long)__builtin_popcountll(r_m)); atomicAdd(&g_lane_stats[32 + d], 1ull); }
+          if (s_m) { atomicAdd(&g_lane_stats[16 + d], (unsigned long long)__builtin_popcountll(s_m)); atomicAdd(&g_lane_stats[48 + d], 1ull); }
+        }
+      }
+      const mask_t img_m = BALLOT(in_image);
+      if (lane == 0) {
+        const uint32_t n_live = (uint32_t)__builtin_popcountll(active_m);
+        atomicAdd(&g_lane_stats[64 + ((n_live - 1u) >> 3)], 1ull);
+        atomicAdd(&g_lane_stats[72], 1ull);
+        atomicAdd(&g_lane_stats[73], (unsigned long long)n_live);
+        if (kinds > 1u) atomicAdd(&g_lane_stats[76], 1ull);
+        if (first_trip) { atomicAdd(&g_lane_stats[74], 1ull); atomicAdd(&g_lane_stats[75], (unsigned long long)__builtin_popcountll(img_m)); }
+      }
+    }
 
     // =====================================================================
     // ray_cast (ray_cast.hpp:29-55): nearest hit of (ro, rd) over all objects
@@ -2032,6 +2066,20 @@ extern "C" int ctr_debug_profile_read(uint64_t *out128, int reset) {
   return CTR_OK;
 }
 #endif
+
+// live-lane statistics of the CTR_VAR_STATS launches since the last reset (g_lane_stats above): 80 words
+extern "C" int ctr_debug_lane_stats(uint64_t *out80, int reset) {
+  if (!out80) return CTR_E_INVALID;
+  unsigned long long h[80];
+  if (hipDeviceSynchronize() != hipSuccess) return CTR_E_INVALID;
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lane_stats), sizeof(h)) != hipSuccess) return CTR_E_INVALID;
+  for (int q = 0; q < 80; q++) out80[q] = h[q];
+  if (reset) {
+    for (int q = 0; q < 80; q++) h[q] = 0ull;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), h, sizeof(h)) != hipSuccess) return CTR_E_INVALID;
+  }
+  return CTR_OK;
+}
 
 extern "C" int ctr_selftest_exact_math(uint64_t *n_mismatch) {
   if (!n_mismatch) return CTR_E_INVALID;

@@ -287,6 +287,14 @@ int ctr_selftest_exact_math(uint64_t *n_mismatch);
  * [13] / [14]: per mesh entry the largest number of node visits / triangle tests any ONE lane had a use for, summed —
  * what a walk by every lane for itself would take in wave steps (the bound on a per-lane walk). */
 int ctr_last_counters(ctr_scene *scene, uint64_t *out16);
+/* Diagnostic: how many of a wave's 64 lanes are alive, trip by trip, in the CTR_VAR_STATS launches since the last reset
+ * (one lane = one pixel for the pixel's whole life; the reference's recursion, inc/shading.hpp:126-150, is what makes
+ * lanes finish at different times).  80 words: [0..15] lanes casting a radiance ray at recursion depth d (0 = primary),
+ * summed over the trips; [16..31] lanes casting a shadow ray for a hit at depth d; [32..47] / [48..63] trips in which at
+ * least one lane casts such a ray; [64..71] trips by number of live lanes (1-8, 9-16, ... 57-64); [72] trips; [73] live
+ * lanes summed over the trips; [74] waves; [75] lanes inside the image summed over the waves; [76] trips whose live lanes
+ * cast for more than one (kind, depth).  Process-wide (one table per device code object), not per scene handle. */
+int ctr_debug_lane_stats(uint64_t *out80, int reset);
 /* ctr_render plus a FOURTH output: the texture coordinates ray_cast hands back for the primary hit (its tex_coords,
  * inc/ray_cast.hpp:47 — triangle::uv_for, plane::uv_for, the sphere's atan2 / asin pair, a mesh's (hit.x, hit.y);
  * inc/default_schema.hpp:37-46,138-139,169-178,246-249), uv2 = 2 floats per pixel, row-major like depth, (0, 0) on a

@@ -295,3 +295,96 @@ def test_bench_default_line_two_ranks_on_one_gpu(ca):
     c4 = line["config"]["c4_strong"]
     assert c4["n_gpus"] == 2 and c4["rays_per_frame"] == 520093696 and c4["frame_ms"] > 0
     assert line["roofline"]["frac"] is None          # a per-launch fraction is claimed for the one-GPU workload only
+
+
+def test_bench_plain_command_starts_its_own_ranks(ca):
+    """`python3 bench.py --gpus 2 ...` with NO launcher in the command and no RANK / WORLD_SIZE in the environment — the form
+    the driver may use — must start the two ranks itself (a child `torch.distributed.run`, before any GPU call), relay rank
+    0's ONE JSON line and the child's exit code.  Rehearsed on the one GPU (both ranks on device 0, gloo for RCCL)."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CUTRACE_BENCH_SHARE_GPU="1", CUTRACE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--check",
+           "--no-extras", "--skip-probe"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "gathered frame(s) bitwise equal" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["frames_per_step"] == 2
+    d = line["config"]["dist"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["devices"] == [0, 0] and d["shared_gpu_rehearsal"]
+    assert "bench.py itself" in d["launched_by"]
+    # and a failing child is not swallowed: an unknown scene makes every rank exit non-zero
+    bad = subprocess.run(cmd + ["--scene", "scene/no_such_scene.json"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
+
+
+def test_one_device_mixes_async_and_synchronous_frames(ca):
+    """with ONE device and CTR_VAR_NO_DIRECT a page-locked destination takes the asynchronous path
+    (render stream + transfer stream) while a pageable one takes the synchronous ctr_render shortcut on the null stream.
+    Alternating the two with two frames in flight used to let two launches of ONE scene handle overlap (shared counter
+    shards, cost table, dispatch order).  The shortcut now drains the streams first: every frame and every ray count must
+    equal the synchronous render, whatever the order."""
+    s = load_scene(ca, "bunny", 640, 360)
+    m = ca.MultiScene(s, [0])
+    bs = (5, 2, 4, 3, 5, 1, 4, 2)
+    want = [m.render(bounces=b) for b in bs]
+    want = [{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for r in want]
+    m.set_variant(ca.VAR_NO_DIRECT)
+    pin = [m.alloc_frame() for _ in range(2)]
+    page = [dict(depth=np.empty((360, 640), np.float32), color=np.empty((360, 640, 3), np.float32),
+                 normal=np.empty((360, 640, 3), np.float32)) for _ in range(2)]
+    dest = [pin[0], page[0], pin[1], page[1], page[0], pin[0], pin[1], page[1]]   # async, sync, async, sync, sync, async ...
+    m.submit(dest[0], bounces=bs[0])
+    for k in range(1, len(bs) + 1):
+        if k < len(bs):
+            m.submit(dest[k], bounces=bs[k])
+        st = m.wait()
+        got = dest[k - 1]
+        for key in ("depth", "color", "normal"):
+            assert same_bits(got[key], want[k - 1][key]), (k - 1, key)
+        assert st["ray_count"] == want[k - 1]["ray_count"] and st["max_depth"] == want[k - 1]["max_depth"], k - 1
+        got["depth"][:] = 0.0
+    for f in pin:
+        m.free_frame(f)
+    m.close()
+
+
+def test_pipelined_submit_wait_over_the_rccl_branch(ca):
+    """The RCCL branch of ctr_multi_submit (per-device transfer stream, ev_moved recorded after the grouped ncclSend /
+    ncclRecv) with two frames in flight — on the one GPU as a one-rank self send/recv (CUTRACE_MULTI_TRANSPORT=rccl-self)."""
+    s = load_scene(ca, "bunny", 320, 180)
+    os.environ["CUTRACE_MULTI_TRANSPORT"] = "rccl-self"
+    try:
+        m = ca.MultiScene(s, [0])
+    finally:
+        del os.environ["CUTRACE_MULTI_TRANSPORT"]
+    if m.transport != "rccl-self":
+        m.close()
+        pytest.skip("librccl.so could not be loaded on this box")
+    bs = (2, 4, 3, 5, 1, 4)
+    ref = ca.DeviceScene(s)
+    want = [ref.render(bounces=b) for b in bs]
+    for pinned in (True, False):
+        if pinned:
+            frames = [m.alloc_frame() for _ in range(3)]
+        else:
+            frames = [dict(depth=np.empty((180, 320), np.float32), color=np.empty((180, 320, 3), np.float32),
+                           normal=np.empty((180, 320, 3), np.float32)) for _ in range(3)]
+        m.submit(frames[0], bounces=bs[0])
+        for k in range(1, len(bs) + 1):
+            if k < len(bs):
+                m.submit(frames[k % 3], bounces=bs[k])
+            st = m.wait()
+            got = frames[(k - 1) % 3]
+            for key in ("depth", "color", "normal"):
+                assert same_bits(got[key], want[k - 1][key]), (pinned, k - 1, key)
+            assert st["ray_count"] == want[k - 1]["ray_count"]
+            got["depth"][:] = 0.0
+        if pinned:
+            for f in frames:
+                m.free_frame(f)
+    m.close()
