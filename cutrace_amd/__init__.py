@@ -25,6 +25,7 @@ VAR_NO_REORDER = 256
 VAR_NO_OCC6 = 512
 VAR_NO_DIRECT = 1024
 VAR_IMAGE_ORDER_FIRST = 2048
+VAR_MERGE = 4096
 
 
 @contextlib.contextmanager
@@ -259,7 +260,8 @@ class DeviceScene:
         out = {"wave_trips": trips, "live_lanes_per_trip": live / trips if trips else None,
                "live_fraction": live / (64.0 * trips) if trips else None,
                "live_fraction_of_in_image_lanes": (live / trips) / (c[75] / c[74]) if trips and c[74] and c[75] else None,
-               "trips_by_live_lanes_1_8_to_57_64": c[64:72], "trips_mixing_kinds": c[76], "waves": c[74]}
+               "trips_by_live_lanes_1_8_to_57_64": c[64:72], "trips_mixing_kinds": c[76], "waves": c[74],
+               "merged_walks": c[78], "merged_walks_redone": c[77]}
         kinds = {}
         for d in range(16):
             for name, base in (("radiance", 0), ("shadow", 16)):

@@ -149,6 +149,21 @@ struct ctr_scene {
     bool linear = false;         // its nodes currently carry unbounded boxes
   };
   std::vector<MeshGuard> guards;
+  // ONE four-wide tree over the triangles of ALL meshes (scenes with 2..255 non-empty meshes; render_kernel.hip "merged
+  // walk"): its records are appended to d_tris / d_nodes4, a pseudo mesh record at d_meshes[n_mesh] leads to them, and
+  // d_meshes[n_mesh + 1 + r] is mesh r in SCENE order (a merged triangle's key names r in its upper 8 bits).
+  struct Merged {
+    bool built = false;      // the structures exist
+    bool usable = false;     // ... and may be walked (refresh_linear_meshes: no mesh went linear, the guard records fit)
+    uint32_t tri_begin = 0, tri_count = 0, node_begin = 0, node_count = 0;
+    std::vector<uint32_t> slot_of;  // per mesh rank: first index of its triangles in a (rank, file index) numbering
+    std::vector<uint32_t> where;    // merged position of triangle (rank, file index) -> tri_begin-relative record index
+    std::vector<uint32_t> guarded;  // keys currently in the guard records
+  } merged;
+  uint32_t min_merge_meshes() const {
+    static const uint32_t v = [] { const char *e = getenv("CUTRACE_MERGE_MIN_MESHES"); return e ? (uint32_t)atol(e) : 2u; }();
+    return v;
+  }
   std::vector<DNode4> h_nodes4;  // the real boxes
   std::vector<DTri> h_tris;
   std::vector<float> h_gn;
@@ -237,7 +252,8 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.oloop = s->d_oloop;
   L.meshes = s->d_meshes;
   L.n_mesh = s->n_mesh;
-  L.tlas_root = s->tlas_root;
+  L.tlas_root = s->tlas_root;          // (use_merged_tree, once the launch's variant is known, may put the merged tree here)
+  L.tlas_root_regular = s->tlas_root;
   L.tlas_begin = s->tlas_begin;
   for (int q = 0; q < 3; q++) { L.tl_mn[q] = s->tl_mn[q]; L.tl_mx[q] = s->tl_mx[q]; }
   L.planes = s->d_planes;
@@ -263,6 +279,18 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.first_frame = 0;
   L.n_frames = 1;
   L.frame_stride_px = 0;
+}
+
+// The merged tree (CTR_VAR_MERGE) when the scene has one and nothing speaks against it (ctr_scene::Merged): a BVH walk of
+// the shipped kind, frame leaving through device buffers.  The top-level tree over the meshes stays the fallback the kernel
+// itself takes for a cast the merged walk cannot decide (render_kernel.hip "merged walk").
+void use_merged_tree(const ctr_scene *s, RenderLaunch &L) {
+  const bool bvh_walk = (L.variant & (KV_BVH | KV_STATS)) && !(L.variant & (KV_COUNT | KV_UV));
+  if ((s->user_variant & CTR_VAR_MERGE) && s->merged.built && s->merged.usable && bvh_walk && !L.group_done &&
+      (L.variant & KV_PREFILTER || (L.variant & KV_STATS))) {
+    L.variant |= KV_MERGE;
+    L.tlas_root = BVH_LEAF_FLAG | s->n_mesh;
+  }
 }
 
 // Attach the tile-order buffers to a launch: use the stored order when the launch has the shape the
@@ -359,6 +387,7 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
 // are large meshes, and single rays (not families) that meet a triangle's plane by numerical coincidence — per (ray,
 // triangle) pair a ~1e-9 event that no full-size comparison or fuzz run has shown yet.
 #define CTR_GUARD_SLOTS 64u
+#define CTR_MERGED_SPARE_NODES ((CTR_GUARD_SLOTS + 2u) / 3u)  // the merged tree: three meshes' guard leaves per spare node
 #define CTR_MIRROR_MESH_TRIS 16u
 #define CTR_VIRTUAL_EYES_MAX 96u
 int refresh_linear_meshes(ctr_scene *s) {
@@ -406,8 +435,12 @@ int refresh_linear_meshes(ctr_scene *s) {
         for (size_t m = 0; m < mirrors.size(); m++)
           if (m != f.second) origins.push_back(image(f.first, mirrors[m]));
   }
+  std::vector<uint32_t> m_keys;  // merged tree: the keys (mesh rank << 24 | file index) of every mesh's risky triangles
+  bool m_any_linear = false;
+  uint32_t rank = 0;             // of the current mesh among the non-empty meshes, scene order (guards are in scene order)
   for (ctr_scene::MeshGuard &g : s->guards) {
     if (g.mesh_pos < 0) continue;
+    const uint32_t g_rank = rank++;
     std::vector<uint32_t> risky;
     const size_t nt = g.planes.size() / 7;
     for (size_t t = 0; t < nt; t++) {
@@ -433,6 +466,9 @@ int refresh_linear_meshes(ctr_scene *s) {
       if (hit) risky.push_back((uint32_t)t);
     }
     const bool want_linear = risky.size() > CTR_GUARD_SLOTS;
+    if (want_linear) m_any_linear = true;
+    else
+      for (uint32_t t : risky) m_keys.push_back((g_rank << 24) | s->h_tris[g.tri_begin + t].orig);
     if (want_linear) risky.clear();
     if (want_linear != g.linear && g.node_count) {
       std::vector<DNode4> nn(s->h_nodes4.begin() + g.node_begin, s->h_nodes4.begin() + g.node_begin + g.node_count);
@@ -474,6 +510,62 @@ int refresh_linear_meshes(ctr_scene *s) {
       HIP_TRY(hipMemcpy(s->d_meshes + g.mesh_pos, &s->h_meshes[g.mesh_pos], sizeof(DObj), hipMemcpyHostToDevice));
       HIP_TRY(hipMemcpy(s->d_objs + g.obj_index, &s->h_objs[g.obj_index], sizeof(DObj), hipMemcpyHostToDevice));
       g.guarded = risky;
+    }
+  }
+  // ---- the merged tree: the same guard, one set of spare records for the triangles of all meshes; a mesh that went
+  //      linear or more risky triangles than records -> the merged tree is not walked (fill_launch) ----
+  if (getenv("CUTRACE_DEBUG_GUARDS")) {
+    size_t per_mesh = 0;
+    for (const ctr_scene::MeshGuard &g : s->guards) per_mesh += g.guarded.size();
+    fprintf(stderr, "cutrace_amd guards: %zu origins (eyes + mirror images), %zu mirrors, %zu guard records over %zu meshes, merged keys %zu, linear %d\n",
+            origins.size(), mirrors.size(), per_mesh, s->guards.size(), m_keys.size(), (int)m_any_linear);
+  }
+  if (s->merged.built) {
+    ctr_scene::Merged &M = s->merged;
+    M.usable = !m_any_linear && m_keys.size() <= CTR_GUARD_SLOTS;
+    if (M.usable && m_keys != M.guarded) {
+      const uint32_t slot0 = M.tri_begin + M.tri_count;
+      for (size_t k = 0; k < m_keys.size(); k++)
+        s->h_tris[slot0 + k] = s->h_tris[M.tri_begin + M.where[M.slot_of[m_keys[k] >> 24] + (m_keys[k] & 0xFFFFFFu)]];
+      if (!m_keys.empty()) {
+        HIP_TRY(hipMemcpy(s->d_tris + slot0, &s->h_tris[slot0], m_keys.size() * sizeof(DTri), hipMemcpyHostToDevice));
+        // The walk starts at a chain of spare nodes before the root.  A spare node holds the guard leaves of up to three
+        // meshes, each behind the box of ITS MESH — the reference shows a mesh's triangles only to rays that pass that
+        // box (default_schema.hpp:126), so the box is exactly as far as a guard record has to reach (behind an unbounded
+        // box every cast of the frame would test every guard record of every mesh: a handful of them doubled the 16-mesh
+        // frame's triangle tests) — and, as its fourth child, the next spare node or the root, unbounded.
+        struct Group { uint32_t rank, first, count; };
+        std::vector<Group> groups;
+        for (size_t k = 0; k < m_keys.size(); k++) {
+          const uint32_t r = m_keys[k] >> 24;
+          if (groups.empty() || groups.back().rank != r) groups.push_back({r, (uint32_t)k, 0u});
+          groups.back().count++;
+        }
+        const uint32_t n_spare = (uint32_t)((groups.size() + 2) / 3);
+        std::vector<DNode4> chain(n_spare);
+        for (uint32_t j = 0; j < n_spare; j++) {
+          DNode4 &g4 = chain[j];
+          memset(&g4, 0, sizeof(g4));
+          for (int c = 0; c < 4; c++) {
+            for (int a = 0; a < 3; a++) { g4.lo[a][c] = 3.4028235e38f; g4.hi[a][c] = 3.4028235e38f; }
+            g4.child[c] = BVH_LEAF_FLAG;
+          }
+          for (int c = 0; c < 3; c++) {
+            const size_t gi = (size_t)3 * j + c;
+            if (gi >= groups.size()) break;
+            const DObj &Rm = s->h_meshes[s->n_mesh + 1u + groups[gi].rank];
+            for (int a = 0; a < 3; a++) { g4.lo[a][c] = Rm.f[a]; g4.hi[a][c] = Rm.f[3 + a]; }
+            g4.child[c] = BVH_LEAF_FLAG | (groups[gi].count << 24) | (M.tri_count + groups[gi].first);
+          }
+          for (int a = 0; a < 3; a++) { g4.lo[a][3] = -3.0e38f; g4.hi[a][3] = 3.0e38f; }
+          g4.child[3] = (j + 1 < n_spare) ? (M.node_count + j + 1) : 0u;  // the next spare node, or the root
+        }
+        HIP_TRY(hipMemcpy(s->d_nodes4 + M.node_begin + M.node_count, chain.data(), chain.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+      }
+      DObj &P = s->h_meshes[s->n_mesh];
+      P.bvh_root = m_keys.empty() ? 0u : M.node_count;
+      HIP_TRY(hipMemcpy(s->d_meshes + s->n_mesh, &P, sizeof(DObj), hipMemcpyHostToDevice));
+      M.guarded = m_keys;
     }
   }
   return CTR_OK;
@@ -748,6 +840,80 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
       for (ctr_scene::MeshGuard &g : guards)
         if (g.obj_index == meshes[pos].index) g.mesh_pos = (int)pos;
   }
+  // ---- ONE four-wide tree over the triangles of all meshes (render_kernel.hip "merged walk") ----
+  // With several meshes a cast otherwise walks the top-level tree, runs the reference's AABB test per mesh it reaches and
+  // sets up a walk per mesh it enters (a fifth of the vector and the densest scalar code of the 16-mesh frame).  The merged
+  // tree's records carry (mesh rank << 24 | file index) as their tie-break key — the reference's (object, triangle) order
+  // as one integer — and the mesh's own AABB test (default_schema.hpp:99-114: a ray that fails it misses the mesh whatever
+  // its triangles say) is applied afterwards, to the lanes the walk found something for.
+  ctr_scene::Merged merged;
+  std::vector<DObj> by_rank;  // non-empty meshes in scene order
+  for (const DObj &O : objs)
+    if (O.type == CTR_OBJ_MESH && O.tri_count) by_rank.push_back(O);
+  {
+    uint64_t total = 0;
+    for (const DObj &O : by_rank) total += O.tri_count;
+    if (by_rank.size() >= 2 && by_rank.size() <= CTR_MERGE_MAX_MESHES && total <= 0xFFFFFFull) {
+      std::vector<BvhInput> prims;
+      std::vector<std::pair<uint32_t, uint32_t>> who;  // (rank, file index) of prims[k]
+      prims.reserve(total);
+      who.reserve(total);
+      for (uint32_t r = 0; r < by_rank.size(); r++) {
+        merged.slot_of.push_back((uint32_t)prims.size());
+        const ctr_object &o = d->objects[by_rank[r].index];
+        const ctr_triangle *src = d->triangles + o.tri_begin;
+        for (uint32_t k = 0; k < (uint32_t)o.tri_count; k++) {
+          const ctr_vec3 *v[3] = {&src[k].p1, &src[k].p2, &src[k].p3};
+          BvhInput b;
+          for (int a = 0; a < 3; a++) {
+            const float c0 = (&v[0]->x)[a], c1 = (&v[1]->x)[a], c2 = (&v[2]->x)[a];
+            b.mn[a] = fminf(c0, fminf(c1, c2));
+            b.mx[a] = fmaxf(c0, fmaxf(c1, c2));
+            b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
+          }
+          prims.push_back(b);
+          who.push_back({r, k});
+        }
+      }
+      std::vector<DNode4> mnodes;
+      std::vector<uint32_t> order;
+      bvh4_build(prims, BVH_LEAF, mnodes, order);
+      merged.built = true;
+      merged.tri_begin = (uint32_t)tris.size();
+      merged.tri_count = (uint32_t)total;
+      merged.node_begin = (uint32_t)nodes4.size();
+      merged.node_count = (uint32_t)mnodes.size();
+      nodes4.insert(nodes4.end(), mnodes.begin(), mnodes.end());
+      for (uint32_t k = 0; k < CTR_MERGED_SPARE_NODES; k++) {  // the spare nodes (guard records, refresh_linear_meshes)
+        nodes4.emplace_back();
+        memset(&nodes4.back(), 0, sizeof(DNode4));
+      }
+      tris.resize(tris.size() + total + CTR_GUARD_SLOTS);
+      gn.resize(4 * tris.size());  // (unused for the merged records: normals are looked up in the mesh's own range)
+      merged.where.resize(total);
+      float dummy_gn[4];
+      for (uint32_t k = 0; k < (uint32_t)total; k++) {
+        const uint32_t r = who[order[k]].first, f = who[order[k]].second;
+        const ctr_triangle &t = d->triangles[d->objects[by_rank[r].index].tri_begin + f];
+        make_tri(t.p1, t.p2, t.p3, (r << 24) | f, tris[merged.tri_begin + k], dummy_gn);
+        merged.where[merged.slot_of[r] + f] = k;
+      }
+      for (uint32_t k = 0; k < CTR_GUARD_SLOTS; k++) tris[merged.tri_begin + total + k] = tris[merged.tri_begin];
+      // the pseudo mesh record: the kernel's mesh code walks it like a mesh whose AABB every lane passes
+      DObj P;
+      memset(&P, 0, sizeof(P));
+      P.type = CTR_OBJ_MERGED;
+      P.tri_begin = merged.tri_begin;
+      P.tri_count = merged.tri_count;
+      P.node_begin = merged.node_begin;
+      P.node_count = merged.node_count;
+      P.bvh_root = 0;
+      P.index = 0xFFFFFFFFu;
+      for (int a = 0; a < 3; a++) { P.f[a] = tl_mn[a]; P.f[3 + a] = tl_mx[a]; }  // (margin of the box tests: the box of all meshes)
+      meshes.push_back(P);
+      for (const DObj &O : by_rank) meshes.push_back(O);
+    }
+  }
   std::vector<DLight> lights(d->n_lights);
   for (uint64_t i = 0; i < d->n_lights; i++) {
     const ctr_light &l = d->lights[i];
@@ -789,7 +955,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   };
   hipError_t er;
   s->n_oloop = (uint32_t)oloop.size();
-  s->n_mesh = (uint32_t)meshes.size();
+  s->n_mesh = (uint32_t)meshes_in.size();  // (meshes[] may continue with the merged pseudo mesh and the meshes in scene order)
   s->tlas_root = tlas_root;
   s->tlas_begin = tlas_begin;
   for (int q = 0; q < 3; q++) { s->tl_mn[q] = tl_mn[q]; s->tl_mx[q] = tl_mx[q]; }
@@ -815,6 +981,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   }
   s->n_cams = 1;
   s->guards = std::move(guards);
+  s->merged = std::move(merged);
   s->h_nodes4 = nodes4;
   s->h_tris = tris;
   s->h_gn = gn;
@@ -894,7 +1061,7 @@ int ctr_scene_set_size(ctr_scene *s, uint64_t w, uint64_t h) {
 int ctr_set_variant(ctr_scene *s, uint32_t bits) {
   if (!s) return fail(CTR_E_INVALID, "null scene");
   constexpr uint32_t KNOWN = CTR_VAR_NO_PREFILTER | CTR_VAR_NO_ANYHIT | CTR_VAR_NO_CLUSTER | CTR_VAR_STATS | CTR_VAR_EXACT_POW |
-                             CTR_VAR_NO_REORDER | CTR_VAR_NO_OCC6 | CTR_VAR_NO_DIRECT | CTR_VAR_IMAGE_ORDER_FIRST;
+                             CTR_VAR_NO_REORDER | CTR_VAR_NO_OCC6 | CTR_VAR_NO_DIRECT | CTR_VAR_IMAGE_ORDER_FIRST | CTR_VAR_MERGE;
   if (bits & ~KNOWN) return fail(CTR_E_INVALID, "ctr_set_variant: unknown variant bits " + std::to_string(bits & ~KNOWN));
   s->user_variant = bits;
   return CTR_OK;
@@ -938,6 +1105,7 @@ int ctr_render_device_batch(ctr_scene *s, float fudge, int bounces, const ctr_ro
   L.normal = (float *)d_normal3;
   L.counters = (unsigned long long *)d_counters;
   L.variant = s->kernel_variant(false);
+  use_merged_tree(s, L);
   {
     std::lock_guard<std::mutex> lk(s->mtx);
     if ((st = attach_order(s, L, false))) return st;
@@ -968,7 +1136,8 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   // "Host delivery"), so the 28 bytes per pixel cross PCIe underneath the rendering instead of in a DMA after it.
   // Any other destination: device buffers + copies, below.
   float *zd = nullptr, *zc = nullptr, *zn = nullptr;
-  const bool direct = px && depth && color3 && normal3 && !count && !uv2 && !(s->user_variant & (CTR_VAR_NO_DIRECT | CTR_VAR_STATS)) &&
+  const bool merge_wanted = (s->user_variant & CTR_VAR_MERGE) && s->merged.built && s->merged.usable;  // (no delivering build of it)
+  const bool direct = px && depth && color3 && normal3 && !count && !uv2 && !(s->user_variant & (CTR_VAR_NO_DIRECT | CTR_VAR_STATS)) && !merge_wanted &&
                       ctr_host_delivery_available(s->kernel_variant(false)) &&
                       is_pinned(depth) && is_pinned(depth + px - 1) && is_pinned(color3) && is_pinned(color3 + 3 * px - 1) &&
                       is_pinned(normal3) && is_pinned(normal3 + 3 * px - 1) && device_view(depth, &zd) &&
@@ -1014,6 +1183,7 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
     L.uv = s->d_uv;
     L.variant = (L.variant & (KV_ANYHIT | KV_FASTPOW)) | KV_PREFILTER | KV_BVH | KV_UV;
   }
+  use_merged_tree(s, L);
   if ((st = attach_order(s, L, count))) return st;
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), nullptr));
   HIP_TRY(hipEventRecord(s->ev0, nullptr));

@@ -98,6 +98,8 @@ __device__ unsigned int g_prof[128];  // executions of the CTR_MARK segments, su
 //   [64..71] trips by the number of live lanes: 1-8, 9-16, ..., 57-64
 //   [72] trips, [73] live lanes summed over the trips, [74] waves, [75] lanes inside the image summed over the waves,
 //   [76] trips in which the live lanes cast for more than one (kind, depth)
+//   [77] casts the merged walk handed back to the two-level walk (a mesh's AABB test failed for a lane the walk had decided,
+//        or a mesh's nearest valid t equalled min_t), [78] casts that went through the merged walk
 __device__ unsigned long long g_lane_stats[80];
 
 // ---- execution profile of the source's straight-line segments (scripts/dynamic_mix.py) ----
@@ -294,7 +296,7 @@ struct KArgs {
   const CADDR DMat *mats;
   uint32_t n_light;
   int bounces;
-  uint32_t n_obj, pad0;
+  uint32_t n_obj, tlas_root2;  // tlas_root2: the top-level tree over the meshes when tlas_root (hot block) names the merged tree
   const CADDR DObj *oloop;     // spheres and stand-alone triangles (sequential loop)
   const CADDR DObj *meshes;    // meshes with >= 1 triangle, in top-level-BVH leaf order
   uint32_t tlas_begin;
@@ -372,6 +374,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
   constexpr bool HOSTOUT = (KV & KV_HOSTOUT) != 0;  // "Host delivery"
   constexpr bool UV = (KV & KV_UV) != 0;            // ray_cast's tex_coords of the primary cast as a fourth output
+  constexpr bool MERGE = (KV & KV_MERGE) != 0;      // "merged walk": the top-level item may be the pseudo mesh over all meshes' triangles
+  static_assert(!MERGE || BVH, "the merged tree is a BVH walk");
   // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
   // prefilters, [3] exact tests, [4] mesh entries (AABB ballot != 0), [5] sum of active lanes per cast,
   // and how many of the 64 lanes had a use for the wave-level work: [6] lanes whose ray meets one of the
@@ -772,6 +776,53 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     if (k_mesh != 0u) {
       uint32_t t_pend = k_tlas_root;             // next top-level item: inner node or mesh leaf
       uint32_t t_stack_v = 0, t_sp = 0;        // wave-uniform stack in the lanes of one VGPR
+      // ---- mesh::bound_intersects, default_schema.hpp:99-114, for the lanes in `lanes` -> the lanes that pass ----
+      // The reference's slab test needs three IEEE divisions (1/dir) per ray.  With 1-ulp
+      // reciprocals every t is within 3 ulp of the exact one and tmin/tmax are 1-Lipschitz in
+      // the t's, so lanes whose tmin/tmax differ by more than dl = 2^-20 * max|t| are decided
+      // without them; only borderline lanes (or NaN/inf: axis-parallel rays) take the exact path.
+      // (site 0: a mesh of the top-level walk; site 1: the merged walk's verification)
+      auto box_test = [&](const CADDR DObj &R, mask_t lanes, auto site) -> mask_t {
+        constexpr int MK = decltype(site)::value ? 83 : 18;
+        (void)MK;
+        const float a1x = (R.f[0] - ro.x) * ria.x, a2x = (R.f[3] - ro.x) * ria.x;
+        const float a1y = (R.f[1] - ro.y) * ria.y, a2y = (R.f[4] - ro.y) * ria.y;
+        const float a1z = (R.f[2] - ro.z) * ria.z, a2z = (R.f[5] - ro.z) * ria.z;
+        const float lo_a = fmaxf(fmaxf(fmaxf(fminf(a1x, a2x), fminf(a1y, a2y)), fminf(a1z, a2z)), 0.0f);
+        const float hi_a = fminf(fminf(fmaxf(a1x, a2x), fmaxf(a1y, a2y)), fmaxf(a1z, a2z));
+        const float tabs = fmaxf(fmaxf(fmaxf(fabsf(a1x), fabsf(a2x)), fmaxf(fabsf(a1y), fabsf(a2y))),
+                                 fmaxf(fabsf(a1z), fabsf(a2z)));
+        const float dl = tabs * 0x1p-20f;
+        const mask_t def_hit = FCMP(lo_a + dl, hi_a, FC_OLT);
+        const mask_t def_miss = FCMP(lo_a - dl, hi_a, FC_OGT);
+        // axis-parallel rays always take the exact path: the reference's inf/NaN min/max semantics
+        // (0 x inf when the origin sits exactly on a box face) are not what finite arithmetic gives
+        const mask_t border = lanes & (~(def_hit | def_miss) | FCMP(ria_big, 1e29f, FC_OGE));
+        mask_t pass_m = lanes & def_hit & ~border;
+        if (border != 0ull) {
+          CTR_MARK(MK);  // exact AABB for borderline lanes
+          if (!have_rinv) {  // wave-uniform: the exact reciprocals are computed at most once per cast
+            CTR_MARK(MK + 1);
+            float ox = rd.x, oy = rd.y, oz = rd.z;
+            PIN3(ox, oy, oz);  // keeps the three IEEE divisions in this rarely-taken branch (no hoisting)
+            rinv = mk(1.0f / ox, 1.0f / oy, 1.0f / oz);  // default_schema.hpp:103
+            have_rinv = true;
+          }
+          CTR_MARK(MK + 2);
+          float tmin = 0.0f, tmax = INFINITY;
+          float t1 = (R.f[0] - ro.x) * rinv.x, t2 = (R.f[3] - ro.x) * rinv.x;
+          tmin = smin(smax(t1, tmin), smax(t2, tmin));
+          tmax = smax(smin(t1, tmax), smin(t2, tmax));
+          t1 = (R.f[1] - ro.y) * rinv.y; t2 = (R.f[4] - ro.y) * rinv.y;
+          tmin = smin(smax(t1, tmin), smax(t2, tmin));
+          tmax = smax(smin(t1, tmax), smin(t2, tmax));
+          t1 = (R.f[2] - ro.z) * rinv.z; t2 = (R.f[5] - ro.z) * rinv.z;
+          tmin = smin(smax(t1, tmin), smax(t2, tmin));
+          tmax = smax(smin(t1, tmax), smin(t2, tmax));
+          pass_m |= border & FCMP(tmin, tmax, FC_OLE);
+        }
+        return pass_m;
+      };
       for (;;) {
         TSTAMP(t_tl0);
         if (ANYHIT) {
@@ -856,20 +907,32 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         const uint32_t i = O.index;
         // (the whole record in one round trip: what the walk needs is requested with the box, not after its test)
         const uint32_t o_tri_begin = O.tri_begin, o_tri_count = O.tri_count, o_node_begin = O.node_begin, o_bvh_root = O.bvh_root;
+        const bool merged = MERGE && i == 0xFFFFFFFFu;  // wave-uniform: the pseudo mesh (CTR_OBJ_MERGED) is no object of the scene
         bool ok = false;
         float cand = INFINITY;
         int ctri = -1;
+        int obj_lane = (int)i;
         {
           // Everything in this branch works on 64-bit lane masks (v_cmp results kept in SGPRs and
           // combined on the scalar unit) instead of per-lane booleans.
           const mask_t live_m = alive_m;
-          // ---- mesh::bound_intersects, default_schema.hpp:99-114 ----
-          // The reference's slab test needs three IEEE divisions (1/dir) per ray.  With 1-ulp
-          // reciprocals every t is within 3 ulp of the exact one and tmin/tmax are 1-Lipschitz in
-          // the t's, so lanes whose tmin/tmax differ by more than dl = 2^-20 * max|t| are decided
-          // without them; only borderline lanes (or NaN/inf: axis-parallel rays) take the exact path.
+          // One tree over the triangles of ALL meshes stands behind the pseudo mesh (ctr_api.cpp ctr_scene::Merged): every
+          // live lane enters it; the AABB test of the mesh a lane's triangle belongs to is made after the walk, for the
+          // lanes the walk decided something for ("merged walk" below).  A real mesh: the reference's test first.
           mask_t bb_m;
-          {
+          if (merged) {
+            // (a ray with a NaN or infinite component never meets a triangle — alpha or the numerators of
+            //  default_schema.hpp:59-62 are then not finite and `isfinite(t0)` or a barycentric test fails — but the walk's
+            //  box tests let a NaN through by design, so such a lane would drag its wave through the WHOLE tree on every
+            //  cast; a mesh's own AABB test stops it in the two-level walk.  Reflections off zero-area triangles make
+            //  them: C3-deep ran 15x longer for a handful of such waves)
+            const float fin_chk = ((ro.x * 0.0f + ro.y * 0.0f) + (ro.z * 0.0f + rd.x * 0.0f)) + (rd.y * 0.0f + rd.z * 0.0f);
+            // ... and a ray that misses the box of ALL meshes for certain misses every mesh's box for certain (each lies inside:
+            // its slab distances lie between the union's, so its entry / exit gap is at least the union's and the rounding
+            // of the reference's own test, 3 ulp of distances no larger than the union's, is far below dl).  That gate is
+            // what keeps a ray whose ORIGIN is far away out of the walk — one that left the room through its open side and
+            // met a wall plane a million units off: the box tests' world-space margin (2^-14 x the distance to the meshes)
+            // then exceeds the room, every box test passes and the wave walks the whole tree on each such cast.
             const float a1x = (O.f[0] - ro.x) * ria.x, a2x = (O.f[3] - ro.x) * ria.x;
             const float a1y = (O.f[1] - ro.y) * ria.y, a2y = (O.f[4] - ro.y) * ria.y;
             const float a1z = (O.f[2] - ro.z) * ria.z, a2z = (O.f[5] - ro.z) * ria.z;
@@ -877,36 +940,23 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             const float hi_a = fminf(fminf(fmaxf(a1x, a2x), fmaxf(a1y, a2y)), fmaxf(a1z, a2z));
             const float tabs = fmaxf(fmaxf(fmaxf(fabsf(a1x), fabsf(a2x)), fmaxf(fabsf(a1y), fabsf(a2y))),
                                      fmaxf(fabsf(a1z), fabsf(a2z)));
-            const float dl = tabs * 0x1p-20f;
-            const mask_t def_hit = FCMP(lo_a + dl, hi_a, FC_OLT);
-            const mask_t def_miss = FCMP(lo_a - dl, hi_a, FC_OGT);
-            // axis-parallel rays always take the exact path: the reference's inf/NaN min/max semantics
-            // (0 x inf when the origin sits exactly on a box face) are not what finite arithmetic gives
-            const mask_t border = live_m & (~(def_hit | def_miss) | FCMP(ria_big, 1e29f, FC_OGE));
-            bb_m = live_m & def_hit & ~border;
-            if (border != 0ull) {
-              CTR_MARK(18);  // exact AABB for borderline lanes
-              if (!have_rinv) {  // wave-uniform: the exact reciprocals are computed at most once per cast
-                CTR_MARK(19);
-                float ox = rd.x, oy = rd.y, oz = rd.z;
-                PIN3(ox, oy, oz);  // keeps the three IEEE divisions in this rarely-taken branch (no hoisting)
-                rinv = mk(1.0f / ox, 1.0f / oy, 1.0f / oz);  // default_schema.hpp:103
-                have_rinv = true;
-              }
-              CTR_MARK(20);
-              float tmin = 0.0f, tmax = INFINITY;
-              float t1 = (O.f[0] - ro.x) * rinv.x, t2 = (O.f[3] - ro.x) * rinv.x;
-              tmin = smin(smax(t1, tmin), smax(t2, tmin));
-              tmax = smax(smin(t1, tmax), smin(t2, tmax));
-              t1 = (O.f[1] - ro.y) * rinv.y; t2 = (O.f[4] - ro.y) * rinv.y;
-              tmin = smin(smax(t1, tmin), smax(t2, tmin));
-              tmax = smax(smin(t1, tmax), smin(t2, tmax));
-              t1 = (O.f[2] - ro.z) * rinv.z; t2 = (O.f[5] - ro.z) * rinv.z;
-              tmin = smin(smax(t1, tmin), smax(t2, tmin));
-              tmax = smax(smin(t1, tmax), smin(t2, tmax));
-              bb_m |= border & FCMP(tmin, tmax, FC_OLE);
+            const mask_t def_miss = FCMP(lo_a - tabs * 0x1p-20f, hi_a, FC_OGT) & ~FCMP(ria_big, 1e29f, FC_OGE);
+            bb_m = live_m & FCMP(fin_chk, 0.0f, FC_OEQ) & ~def_miss;
+            // A lane of those that starts more than 16 box sizes away (and still aims at the box: a shadow ray from such a hit
+            // point to a light in the room) gets box margins of 0.1 % of the box and more, growing with its distance: the
+            // cast goes through the two-level walk instead, where the meshes' own AABB tests — exact at any distance —
+            // stand before the walk.
+            const float g_far = fmaxf(fmaxf(fmaxf(fabsf(O.f[0] - ro.x), fabsf(O.f[3] - ro.x)), fmaxf(fabsf(O.f[1] - ro.y), fabsf(O.f[4] - ro.y))),
+                                      fmaxf(fabsf(O.f[2] - ro.z), fabsf(O.f[5] - ro.z)));
+            const float ext16 = 16.0f * fmaxf(fmaxf(O.f[3] - O.f[0], O.f[4] - O.f[1]), O.f[5] - O.f[2]);
+            if ((bb_m & FCMP(g_far, ext16, FC_OGT)) != 0ull) {
+              CTR_MARK(88);
+              if (STATS && lane == 0) atomicAdd(&g_lane_stats[77], 1ull);
+              t_pend = AK->tlas_root2;
+              t_sp = 0u;
+              continue;
             }
-          }
+          } else bb_m = box_test(O, live_m, SITE(0));
           TSTAMP(t_bb);
           TACC(3, t_tl0, t_bb);
           CTR_MARK(21);
@@ -1009,6 +1059,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                   const mask_t occ_m = c_m & in_m & tin_m & ~flat_m & anyhit_m;
                   if (occ_m != 0ull) {
                     CTR_MARK(26);
+                    // (which triangle decided the lane: the merged walk verifies that triangle's mesh afterwards)
+                    if (MERGE) morig = INVB(occ_m) ? T.orig : morig;
                     bb_m &= ~occ_m;  // (retired: best / bobj are set once, where the mesh is left)
                     alive_m &= ~occ_m;
                     c_m &= ~occ_m;
@@ -1061,7 +1113,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
                   // within et of the light distance.
                   if (!exact_t && !(tq + et < light_dist) && !(tq - et >= light_dist)) { CTR_MARK(122); t0 = A0 / alpha; }
                   CTR_MARK(123);
-                  if (t0 > min_t && t0 < light_dist) retire = true;  // (best / bobj: where the mesh is left)
+                  if (t0 > min_t && t0 < light_dist) { retire = true; if (MERGE) morig = T.orig; }  // (best / bobj: where the mesh is left)
                 } else {
                   CTR_MARK(124);
                   // the exact value of t0 matters only if it can beat or tie the nearest hit so far
@@ -1261,6 +1313,43 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             st[9] += (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_nodes);
             st[10] += (uint32_t)__builtin_amdgcn_readfirstlane((int)pl_tris);
           }
+          // ---- merged walk: the AABB test of the meshes the walk found something in ----
+          // The walk above went through ONE tree over the triangles of all meshes; a lane's `morig` now names the triangle
+          // that decided it (nearest valid hit, or the occluder of a deciding shadow ray) as (mesh rank << 24 | file index).
+          // The reference tests a mesh's box BEFORE its triangles (default_schema.hpp:126): a ray that fails it misses the
+          // mesh whatever the triangle test says — possible only within rounding of the box's faces, but then the lane's
+          // result, and everything the walk pruned because of it, is wrong.  So: per mesh that decided a lane (usually
+          // one or two per cast) the reference's test for those lanes.  Any lane failing it, or a mesh whose nearest valid
+          // t equals min_t exactly (ray_cast.hpp:43 then rejects the whole mesh, strict >), and the cast walks the
+          // scene's two-level structure instead, which has the reference's form — measure-zero events, not a fast path.
+          int i_lane = merged ? 0 : (int)i;   // scene index of the mesh that decided the lane
+          int ctri_lane = (int)(beg + morig); // its triangle's position in the normals array (file order within its mesh)
+          if (MERGE && merged) {
+            CTR_MARK(86);
+            if (STATS && lane == 0) atomicAdd(&g_lane_stats[78], 1ull);
+            mask_t todo = BALLOT(morig != 0xFFFFFFFFu);
+            mask_t bad_m = BALLOT(mt != INFINITY && !(mt > min_t));
+            while (todo != 0ull) {
+              const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)morig, (int)__builtin_ctzll(todo)) >> 24;
+              const mask_t same_m = todo & BALLOT((morig >> 24) == rk);
+              const CADDR DObj &R = AK->meshes[k_mesh + 1u + rk];
+              const uint32_t r_index = R.index, r_beg = R.tri_begin;
+              bad_m |= same_m & ~box_test(R, same_m, SITE(1));
+              if (INVB(same_m)) { i_lane = (int)r_index; ctri_lane = (int)(r_beg + (morig & 0xFFFFFFu)); }
+              todo &= ~same_m;
+            }
+            if (bad_m != 0ull) {
+              CTR_MARK(87);  // this cast again, through the top-level tree and the meshes' own trees
+              if (STATS && lane == 0) atomicAdd(&g_lane_stats[77], 1ull);
+              if (ANYHIT) {
+                alive_m |= bad_m & anyhit_m;  // (a deciding shadow ray whose occluder does not count is alive again)
+                if (INVB(anyhit_m & ~alive_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = i_lane; }
+              }
+              t_pend = AK->tlas_root2;
+              t_sp = 0u;
+              continue;
+            }
+          }
           CTR_MARK(35);  // mesh left
           if (ANYHIT) {
             // lanes retired inside the mesh (deciding shadow rays that met an occluder): the handler only asks
@@ -1269,11 +1358,12 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             // (every deciding shadow ray that has retired by now, in this mesh or before it: writing the same again for the
             //  earlier ones is harmless — the handler never asks which object it was — and saves carrying the mesh's entry
             //  mask through the walk: scalar registers are what this kernel is shortest of)
-            if (INVB(anyhit_m & ~alive_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = (int)i; }
+            if (INVB(anyhit_m & ~alive_m)) { best = fminf(0.5f * light_dist, 1e30f); bobj = i_lane; }
           }
           ok = mt != INFINITY;  // default_schema.hpp:143 (lanes outside the AABB never set mt)
           cand = mt;
-          ctri = (int)(beg + morig);  // gnorm is indexed by the triangle's FILE-order position within its mesh
+          ctri = ctri_lane;  // gnorm is indexed by the triangle's FILE-order position within its mesh
+          obj_lane = i_lane;
 #ifdef CTR_TIMING
           {
             const unsigned long long t_mesh1 = __builtin_readcyclecounter();
@@ -1285,9 +1375,9 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
 
         }
         // ray_cast.hpp:43 — strict <, first object in scene order wins ties
-        if (INVB(alive_m) && ok && cand > min_t && (cand < best || (cand == best && (int)i < bobj))) {
+        if (INVB(alive_m) && ok && cand > min_t && (cand < best || (cand == best && obj_lane < bobj))) {
           best = cand;
-          bobj = (int)i;
+          bobj = obj_lane;
           btri = ctri;
         }
         // (no "a deciding shadow ray with a valid mesh hit stops searching" here: in the any-hit build such a lane never
@@ -1953,6 +2043,7 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.meshes = (const CADDR DObj *)L.meshes;
   A.n_mesh = L.n_mesh;
   A.tlas_root = L.tlas_root;
+  A.tlas_root2 = L.tlas_root_regular;
   A.tlas_begin = L.tlas_begin;
   for (int q = 0; q < 3; q++) { A.tl_mn[q] = L.tl_mn[q]; A.tl_mx[q] = L.tl_mx[q]; }
   A.planes = (const CADDR DPlanePair *)L.planes;
@@ -2129,6 +2220,16 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
     return (L.variant & KV_ANYHIT) ? launch<U | KV_ANYHIT>(L, s) : launch<U>(L, s);
   }
   if (L.variant & KV_COUNT) return launch<KV_PREFILTER | KV_COUNT>(L, s);
+  if (L.variant & KV_MERGE) {
+    // the merged walk (CTR_VAR_MERGE, scenes with several meshes): the shipped walk's variants only
+    constexpr uint32_t M = KV_PREFILTER | KV_BVH | KV_MERGE;
+    const bool any = (L.variant & KV_ANYHIT) != 0;
+    if (L.variant & KV_STATS) return any ? launch<M | KV_ANYHIT | KV_FASTPOW | KV_STATS>(L, s) : launch<M | KV_FASTPOW | KV_STATS>(L, s);
+    if (!(L.variant & KV_FASTPOW)) return any ? launch<M | KV_ANYHIT>(L, s) : launch<M>(L, s);
+    const size_t sb = (size_t)((L.bounces > 0 && L.any_bounce) ? L.bounces : 1) * (L.need_cold_frames ? 10u : 4u) * 64 * sizeof(float);
+    if (any && (L.variant & KV_OCC6) && occ6_fits(sb)) return launch<M | KV_FASTPOW | KV_ANYHIT | KV_OCC6>(L, s);
+    return any ? launch<M | KV_FASTPOW | KV_ANYHIT>(L, s) : launch<M | KV_FASTPOW>(L, s);
+  }
   if (L.variant & KV_STATS)
     return (L.variant & KV_ANYHIT) ? launch<KV_BVH | KV_PREFILTER | KV_ANYHIT | KV_FASTPOW | KV_STATS>(L, s)
                                    : launch<KV_BVH | KV_PREFILTER | KV_FASTPOW | KV_STATS>(L, s);

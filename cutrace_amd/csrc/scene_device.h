@@ -31,7 +31,9 @@ struct DTri {
   float ab[3][2];       // ab[axis][0] = a = p2 - p1, ab[axis][1] = b = p2 - p3: (a, b) of one axis is an aligned SGPR
                         // pair, so that one v_pk_fma_f32 advances a.q and b.q together (prefilter)
   float px, py, pz;     // p2; (px, py) is an aligned pair as well
-  uint32_t orig;        // index of this triangle in the ORIGINAL (file-order) array: tie-break key
+  uint32_t orig;        // index of this triangle in the ORIGINAL (file-order) array: tie-break key.  In the merged tree:
+                        // (rank of its mesh among the scene's meshes << 24) | file index — the reference's order
+                        // (ray_cast.hpp:43 first object wins, default_schema.hpp:134 first triangle wins) as ONE integer
   float nx, ny, nz;     // a x b (prefilter only)
   float ke;             // kappa * emax,   emax = max|component of a,b| (prefilter error scale)
   float ke2;            // kappa * emax^2
@@ -39,6 +41,8 @@ struct DTri {
 };
 static_assert(sizeof(DTri) == 64, "DTri must be one 64-byte line");
 
+#define CTR_OBJ_MERGED 4u  /* device-only: the pseudo mesh that stands for ONE tree over the triangles of all meshes */
+#define CTR_MERGE_MAX_MESHES 255u
 struct DObj {
   uint32_t type;        // CTR_OBJ_*
   uint32_t mat;         // material index
@@ -111,6 +115,7 @@ enum : uint32_t {
   KV_OCC6 = 64u,       // compiled for 6 waves per SIMD instead of 5 (large meshes: latency-bound on scalar-cache misses)
   KV_HOSTOUT = 128u,   // the launch delivers the frame to page-locked host memory itself (RenderLaunch::group_done)
   KV_UV = 256u,        // also write the texture coordinates of the primary hit (ray_cast's tex_coords), RenderLaunch::uv
+  KV_MERGE = 512u,     // the walk may meet the merged pseudo mesh: ONE tree over the triangles of all meshes (CTR_VAR_MERGE)
 };
 
 struct DRows {
@@ -126,8 +131,9 @@ struct DRows {
 struct RenderLaunch {
   const DObj *objs;        // every object, scene order (hit records)
   const DObj *oloop;       // spheres and stand-alone triangles, scene order (sequential loop)
-  const DObj *meshes;      // non-empty meshes in top-level-BVH leaf order
+  const DObj *meshes;      // non-empty meshes in top-level-BVH leaf order; [n_mesh] the merged pseudo mesh, [n_mesh + 1 + r] mesh r in scene order
   uint32_t n_mesh, tlas_root, tlas_begin;
+  uint32_t tlas_root_regular;  // the top-level tree over the meshes when tlas_root names the merged tree (else the same)
   float tl_mn[3], tl_mx[3];
   const DPlanePair *planes;  // n_plane_recs records, the first n_axis_recs of them axis triples
   uint32_t n_oloop, n_plane_recs, n_axis_recs;

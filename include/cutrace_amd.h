@@ -264,6 +264,8 @@ int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
 #define CTR_VAR_NO_REORDER 256u   /* always dispatch tiles in image order (see below) */
 #define CTR_VAR_IMAGE_ORDER_FIRST 2048u /* the first launch of a shape dispatches its tiles in image order instead of centre-out */
 #define CTR_VAR_NO_DIRECT 1024u   /* ctr_render / ctr_render_multi: page-locked destinations get device buffers + DMA instead of delivery by the kernels */
+#define CTR_VAR_MERGE 4096u       /* scenes with 2..255 meshes: walk ONE tree over the triangles of all meshes instead of a tree over the meshes' boxes and
+                                   * then each mesh's own tree.  Same results; measured SLOWER on every shipped config (profiles/r04/exp_merged_tree_ab.txt), so opt-in */
 #define CTR_VAR_NO_OCC6 512u      /* never pick the build compiled for 6 waves per SIMD (chosen for scenes with >= 1000 mesh triangles) */
 /* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
  * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles
@@ -293,7 +295,8 @@ int ctr_last_counters(ctr_scene *scene, uint64_t *out16);
  * summed over the trips; [16..31] lanes casting a shadow ray for a hit at depth d; [32..47] / [48..63] trips in which at
  * least one lane casts such a ray; [64..71] trips by number of live lanes (1-8, 9-16, ... 57-64); [72] trips; [73] live
  * lanes summed over the trips; [74] waves; [75] lanes inside the image summed over the waves; [76] trips whose live lanes
- * cast for more than one (kind, depth).  Process-wide (one table per device code object), not per scene handle. */
+ * cast for more than one (kind, depth); [77] wave casts the merged walk (one tree over all meshes' triangles) handed back
+ * to the two-level walk, [78] wave casts that went through the merged walk.  Process-wide (one table per device code object), not per scene handle. */
 int ctr_debug_lane_stats(uint64_t *out80, int reset);
 /* ctr_render plus a FOURTH output: the texture coordinates ray_cast hands back for the primary hit (its tex_coords,
  * inc/ray_cast.hpp:47 — triangle::uv_for, plane::uv_for, the sphere's atan2 / asin pair, a mesh's (hit.x, hit.y);
