@@ -64,6 +64,10 @@ def parse_args():
                    help="which rank a frame is gathered to when a step has several frames: frame f -> rank f mod N "
                         "(balanced xGMI links and re-interleave work), or always rank 0")
     p.add_argument("--variant", type=int, default=0)
+    p.add_argument("--in-flight", type=int, default=1, choices=[1, 2, 3, 4],
+                   help="2: consecutive steps alternate between two scene handles on two streams, so the first waves of step k+1 "
+                        "fill the slots the tail of step k leaves empty (throughput of a frame sequence; every step still "
+                        "completes inside the timed region).  1 (default, the headline): one launch after the other")
     p.add_argument("--skip-probe", action="store_true",
                    help="skip the untimed image-order launches after the timed region (profiling runs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,7 +86,13 @@ def cpu_baseline(ca, host_scene, bounces, div):
     """Bounded CPU sample: every `div`-th 8-row block of the same frame, all host threads."""
     import oracle  # the checker libraries: this leg is the only place bench.py touches them
     w, h = host_scene.size
-    threads = min(os.cpu_count() or 1, 64)
+    # all hardware threads the process may use (SURVEY §8(d): "1 thread and all hardware threads"; the box's 64-core EPYC shows
+    # 128 with SMT — round 3 capped this at 64), but no more than the checker's own limit of 256 workers
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 256))
     use_ref = oracle.ref_lib() is not None
     fn = oracle.ref_render if use_ref else oracle.oracle_render
     if div <= 0:
@@ -263,6 +273,41 @@ def extras(ca, hs, args, ds):
         # (3c) a MOVING camera (90 frames, eye ~1.5 cm and view ~0.35 deg per frame): every frame is ordered by the costs
         #      of the previous, different frame — against image order (scripts/gpu_campath.py's loop)
         out.update(campath(ca, hs, ds.device))
+    # (3d) what a one-shot `cutrace <scene.json>` pays BEFORE its render (main.cu:21-30: load, cpu_to_gpu, then render):
+    #      ctr_scene_create = host BVH build + flat records + device allocation + upload, for C2, C2-dense and C4; and the
+    #      drop-in CLI's whole wall time for scene/bunny.json (process start, HIP initialisation, load, create, render, three JPGs)
+    if os.path.basename(args.scene) == "bunny.json":
+        import subprocess
+        d = tempfile.mkdtemp()
+        sc = {}
+        for name, path in (("C2 bunny.json (1000 triangles)", os.path.join(ROOT, "scene", "bunny.json")),
+                           ("C2-dense (64000 triangles)", scenes.make_dense_bunny(d, 3, width=w, height=h)),
+                           ("C4 4x4 grid (16 x 1000 triangles)", scenes.make_bunny_grid(tempfile.mkdtemp()))):
+            t0 = time.perf_counter()
+            hsx = ca.HostScene.load(path)
+            t1 = time.perf_counter()
+            ms = []
+            for _ in range(3):
+                t2 = time.perf_counter()
+                x = ca.DeviceScene(hsx, device=ds.device)
+                ms.append((time.perf_counter() - t2) * 1e3)
+                x.close()
+            sc[name] = {"scene_create_ms": min(ms), "scene_create_ms_first": ms[0], "json_and_stl_load_ms": (t1 - t0) * 1e3}
+        out["scene_create_ms"] = sc
+        cli = os.path.join(ROOT, "cutrace_amd", "cutrace")
+        if os.path.exists(cli):
+            cwd = tempfile.mkdtemp()
+            os.symlink(os.path.join(ROOT, "scene"), os.path.join(cwd, "scene"))
+            walls = []
+            line = ""
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, "scene/bunny.json"], cwd=cwd, capture_output=True, text=True, timeout=300)
+                walls.append((time.perf_counter() - t0) * 1e3)
+                line = next((l for l in r.stdout.splitlines() if "ms" in l and "ender" in l), line)
+            out["cli_bunny_json"] = {"wall_ms": min(walls), "wall_ms_first": walls[0], "its_own_timing_line": line.strip(),
+                                     "what": "`cutrace scene/bunny.json` as a process: start, HIP initialisation, JSON + STL load, ctr_scene_create, "
+                                             "ctr_render into page-locked grids, three JPG files"}
     # (4) SURVEY §8(d): bytes the REFERENCE's flat traversal streams for this frame (56 B x objects per ray_cast +
     #     48 B x triangles of every mesh whose AABB the ray hits + 28 B per pixel) — a workload property
     alg_bytes, alg_rays = ds.algorithmic_bytes(bounces=args.bounces)
@@ -427,21 +472,27 @@ def main():
     w, h = hs.size
     sim = args.of if (world == 1 and args.of > 1) else 0
 
-    def measure(hs, scaling, roots, steps, warmup, probe):
+    def measure(hs, scaling, roots, steps, warmup, probe, in_flight=1):
         """One workload through the tiler: -> (ds, tiler, frames, dt_max, rays_step, kern_avg, kern_io)."""
         w, h = hs.size
-        ds = ca.DeviceScene(hs, device=local_rank)  # raises when the HIP library is missing
+        # in_flight == 2: two scene handles (each keeps its own counters, tile costs and dispatch order: launches on ONE handle
+        # must not overlap) on two streams, used alternately
+        handles = [ca.DeviceScene(hs, device=local_rank) for _ in range(in_flight)]  # raises when the HIP library is missing
+        ds = handles[0]
         if args.variant:
-            ds.set_variant(args.variant)
+            for x in handles:
+                x.set_variant(args.variant)
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(in_flight - 1)]
         frames = world if scaling == "weak" else 1
+        n_slots = 2 if in_flight == 1 else 2 * in_flight
         if sim:  # one process plays rank `as_rank` of `of` ranks: same launches, no collective
             frames = sim if scaling == "weak" else 1
-            tiler = FrameTiler(w, h, frames, args.as_rank, sim, dev, roots=roots)
+            tiler = FrameTiler(w, h, frames, args.as_rank, sim, dev, roots=roots, slots=n_slots)
             tiler.gather = lambda slot: None
             tiler.begin = lambda slot: None
-            tiler.finish = lambda: None
+            tiler.finish = lambda: torch.cuda.synchronize(dev)
         else:
-            tiler = FrameTiler(w, h, frames, rank, world, dev, roots=roots)
+            tiler = FrameTiler(w, h, frames, rank, world, dev, roots=roots, slots=n_slots)
         if frames > 1:
             import ctypes
             cam0 = hs.desc.contents.cam
@@ -450,30 +501,34 @@ def main():
                 c = ca.Camera()
                 ctypes.memmove(ctypes.byref(c), ctypes.byref(cam0), ctypes.sizeof(ca.Camera))
                 cams.append(c)
-            ds.set_cameras(cams)
-        counters = torch.zeros(16, dtype=torch.int64, device=dev)
-        stream = torch.cuda.current_stream()
+            for x in handles:
+                x.set_cameras(cams)
+        counters_all = [torch.zeros(16, dtype=torch.int64, device=dev) for _ in range(in_flight)]
+        counters = counters_all[0]
         step_no = [0]
 
         def render_step(events=None):
-            slot = step_no[0] % tiler.slots
+            k = step_no[0]
+            slot = k % tiler.slots
             step_no[0] += 1
-            tiler.begin(slot)  # the gather that last used this half of the double buffer must be done
-            buf = tiler.local[slot]
-            d0, c0, n0, _ = tiler.sec
-            esz = buf.element_size()
-            if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-            # ONE launch renders this rank's rows of all `frames` frames of the step (camera path batch)
-            ds.render_device_batch(buf.data_ptr() + d0 * esz, buf.data_ptr() + c0 * esz, buf.data_ptr() + n0 * esz,
-                                   n_frames=frames, frame_stride_px=tiler.cap * w, d_counters=counters.data_ptr(),
-                                   stream=stream.cuda_stream, fudge=1e-3, bounces=args.bounces, rows=tiler.rows,
-                                   part_stride=tiler.part_stride)
-            if events is not None:
-                e1.record(stream)
-                events.append((e0, e1))
-            tiler.gather(slot)  # asynchronous: overlaps with the next step's rendering
+            hnd, stream = handles[k % in_flight], streams[k % in_flight]
+            with torch.cuda.stream(stream):
+                tiler.begin(slot)  # the gather that last used this part of the buffer ring must be done
+                buf = tiler.local[slot]
+                d0, c0, n0, _ = tiler.sec
+                esz = buf.element_size()
+                if events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                # ONE launch renders this rank's rows of all `frames` frames of the step (camera path batch)
+                hnd.render_device_batch(buf.data_ptr() + d0 * esz, buf.data_ptr() + c0 * esz, buf.data_ptr() + n0 * esz,
+                                        n_frames=frames, frame_stride_px=tiler.cap * w, d_counters=counters_all[k % in_flight].data_ptr(),
+                                        stream=stream.cuda_stream, fudge=1e-3, bounces=args.bounces, rows=tiler.rows,
+                                        part_stride=tiler.part_stride)
+                if events is not None:
+                    e1.record(stream)
+                    events.append((e0, e1))
+                tiler.gather(slot)  # asynchronous: overlaps with the next step's rendering
 
         def barrier():
             tiler.finish()      # every outstanding gather / re-interleave completes INSIDE the timed region
@@ -501,13 +556,15 @@ def main():
         # first launch of a shape costs before the scheduling feedback exists
         kern_io = None
         if probe:
-            ds.set_variant(args.variant | ca.VAR_NO_REORDER)
+            for x in handles:
+                x.set_variant(args.variant | ca.VAR_NO_REORDER)
             ev_io = []
             for _ in range(3):
                 render_step(ev_io)
-            barrier()
+                barrier()
             kern_io = min(a.elapsed_time(b) for a, b in ev_io)
-            ds.set_variant(args.variant)
+            for x in handles:
+                x.set_variant(args.variant)
         t = torch.tensor([dt, float(rays_rank_step), sum(kern_ms) / max(1, len(kern_ms))], dtype=torch.float64, device=dev)
         if world > 1:
             tmax = t.clone()
@@ -520,7 +577,7 @@ def main():
         return ds, tiler, frames, dt_max, rays_step, kern_avg, kern_io
 
     ds, tiler, frames, dt_max, rays_step, kern_avg, kern_io = measure(hs, args.scaling, args.roots, args.steps, args.warmup,
-                                                                       not args.skip_probe)
+                                                                       not args.skip_probe, args.in_flight)
 
     if args.check and not sim:
         import numpy as np
@@ -547,11 +604,19 @@ def main():
         import tempfile
         from cutrace_amd import scenes
         c4_hs = ca.HostScene.load(scenes.make_bunny_grid(tempfile.mkdtemp(prefix=f"c4_r{rank}_")))
-        _, c4_tiler, _, c4_dt, c4_rays, c4_kern, _ = measure(c4_hs, "strong", "rank0", 6, 2, False)
+        # (12 steps after 4 of warm-up: the dispatch order is rebuilt from measured costs over the first launches of a shape, and
+        #  a part of a frame — 5 waves per slot at N = 8 — feels an order that has not settled: 6 steps after 2 read 6 % slower)
+        _, c4_tiler, _, c4_dt, c4_rays, c4_kern, _ = measure(c4_hs, "strong", "rank0", 12, 4, False)
         c4_leg = {"workload": "4x4 bunny grid (16 meshes x 1000 triangles) @4096x4096 bounces=%d, one frame per step row-tiled "
                               "over %d GPU(s), gathered to rank 0" % (args.bounces, world),
-                  "n_gpus": world, "steps": 6, "frame_ms": c4_dt / 6 * 1e3, "mrays_per_s": c4_rays * 6 / c4_dt / 1e6,
+                  "n_gpus": world, "steps": 12, "frame_ms": c4_dt / 12 * 1e3, "mrays_per_s": c4_rays * 12 / c4_dt / 1e6,
                   "rays_per_frame": c4_rays, "kernel_ms_avg_over_ranks": c4_kern}
+        # the same with two frames in flight (--in-flight 2): a rank's part of ONE frame is 5 waves per slot at N = 8 and ends in a
+        # tail of its dearest tiles (one 8x8 tile = one wave, up to 5x the mean); the next frame's first waves fill that tail
+        del c4_tiler
+        _, c4_tiler, _, c4_dt2, c4_rays2, _, _ = measure(c4_hs, "strong", "rank0", 12, 4, False, 2)
+        c4_leg["frame_ms_two_in_flight"] = c4_dt2 / 12 * 1e3
+        c4_leg["mrays_per_s_two_in_flight"] = c4_rays2 * 12 / c4_dt2 / 1e6
         if world == 1:
             c4_ds = ca.DeviceScene(c4_hs, device=local_rank)
             c4_ds.set_variant(ca.VAR_STATS)
@@ -560,6 +625,14 @@ def main():
             c4_leg["live_lanes"] = _live_summary(ca.DeviceScene.lane_stats(reset=True))
             c4_ds.close()
         del c4_tiler
+    two = None
+    if not args.no_extras and args.in_flight == 1 and not sim:
+        # the timed workload once more with two steps in flight (--in-flight 2), untimed for `value`
+        _, t2_tiler, _, t2_dt, t2_rays, _, _ = measure(hs, args.scaling, args.roots, args.steps, args.warmup, False, 2)
+        two = {"ms_per_step": t2_dt / args.steps * 1e3, "mrays_per_s": t2_rays * args.steps / t2_dt / 1e6,
+               "what": "consecutive steps alternate between two scene handles on two streams: the first waves of step k+1 fill the "
+                       "slots the tail of step k leaves empty; `value` above is measured with one launch after the other"}
+        del t2_tiler
     if rank == 0:
         total_rays = rays_step * args.steps
         value = total_rays / dt_max / 1e6
@@ -582,6 +655,9 @@ def main():
             config.update(extras(ca, hs, args, ds))
         if c4_leg:
             config["c4_strong"] = c4_leg
+        if two:
+            config["two_steps_in_flight"] = two
+        config["steps_in_flight"] = args.in_flight
         for tag, key in (("dense64k", "dense_64k_roofline"), ("c4", "c4_roofline")):
             r_ = roofline_from_profiles(PROFILE_WORKLOADS[tag], 0.0, "")
             if r_.get("frac") is not None:  # (constants of the committed PMC passes: that scene is not timed live here)

@@ -153,10 +153,13 @@ struct ctr_scene {
   // walk"): its records are appended to d_tris / d_nodes4, a pseudo mesh record at d_meshes[n_mesh] leads to them, and
   // d_meshes[n_mesh + 1 + r] is mesh r in SCENE order (a merged triangle's key names r in its upper 8 bits).
   struct Merged {
-    bool built = false;      // the structures exist
+    bool reserved = false;   // the scene qualifies (2..255 non-empty meshes) and the device arrays have room for the tree
+    bool built = false;      // the structures exist (build_merged_tree: at the first ctr_set_variant with CTR_VAR_MERGE)
+    uint32_t node_cap = 0;   // room for the tree's nodes in d_nodes4 (the spare nodes follow)
+    std::vector<ctr_triangle> src;  // the meshes' triangles, scene order then file order (kept for the build)
     bool usable = false;     // ... and may be walked (refresh_linear_meshes: no mesh went linear, the guard records fit)
     uint32_t tri_begin = 0, tri_count = 0, node_begin = 0, node_count = 0;
-    std::vector<uint32_t> slot_of;  // per mesh rank: first index of its triangles in a (rank, file index) numbering
+    std::vector<uint32_t> slot_of;  // per mesh rank: first index of its triangles in a (rank, file index) numbering (+ one past the last)
     std::vector<uint32_t> where;    // merged position of triangle (rank, file index) -> tri_begin-relative record index
     std::vector<uint32_t> guarded;  // keys currently in the guard records
   } merged;
@@ -571,6 +574,51 @@ int refresh_linear_meshes(ctr_scene *s) {
   return CTR_OK;
 }
 
+// The merged tree of a scene that has room for it (ctr_scene::Merged, ctr_scene_create): built, uploaded, guarded.
+int build_merged_tree(ctr_scene *s) {
+  ctr_scene::Merged &M = s->merged;
+  if (!M.reserved || M.built) return CTR_OK;
+  const uint32_t total = M.tri_count, n_rank = (uint32_t)M.slot_of.size() - 1;
+  std::vector<BvhInput> prims(total);
+  std::vector<uint32_t> rank_of(total);
+  for (uint32_t r = 0; r < n_rank; r++)
+    for (uint32_t k = M.slot_of[r]; k < M.slot_of[r + 1]; k++) {
+      const ctr_vec3 *v[3] = {&M.src[k].p1, &M.src[k].p2, &M.src[k].p3};
+      BvhInput &b = prims[k];
+      for (int a = 0; a < 3; a++) {
+        const float c0 = (&v[0]->x)[a], c1 = (&v[1]->x)[a], c2 = (&v[2]->x)[a];
+        b.mn[a] = fminf(c0, fminf(c1, c2));
+        b.mx[a] = fmaxf(c0, fmaxf(c1, c2));
+        b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
+      }
+      rank_of[k] = r;
+    }
+  std::vector<DNode4> mnodes;
+  std::vector<uint32_t> order;
+  bvh4_build(prims, BVH_LEAF, mnodes, order);
+  if (mnodes.size() > M.node_cap) return CTR_OK;  // (cannot happen for leaves of up to four triangles; then simply never used)
+  M.node_count = (uint32_t)mnodes.size();
+  std::copy(mnodes.begin(), mnodes.end(), s->h_nodes4.begin() + M.node_begin);
+  M.where.assign(total, 0u);
+  float dummy_gn[4];
+  for (uint32_t k = 0; k < total; k++) {
+    const uint32_t g = order[k], r = rank_of[g], f = g - M.slot_of[r];
+    const ctr_triangle &t = M.src[g];
+    make_tri(t.p1, t.p2, t.p3, (r << 24) | f, s->h_tris[M.tri_begin + k], dummy_gn);
+    M.where[g] = k;
+  }
+  for (uint32_t k = 0; k < CTR_GUARD_SLOTS; k++) s->h_tris[M.tri_begin + total + k] = s->h_tris[M.tri_begin];
+  DObj &P = s->h_meshes[s->n_mesh];
+  P.node_count = M.node_count;
+  P.bvh_root = 0;
+  HIP_TRY(hipMemcpy(s->d_tris + M.tri_begin, &s->h_tris[M.tri_begin], ((size_t)total + CTR_GUARD_SLOTS) * sizeof(DTri), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->d_nodes4 + M.node_begin, &s->h_nodes4[M.node_begin], (size_t)M.node_count * sizeof(DNode4), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->d_meshes + s->n_mesh, &P, sizeof(DObj), hipMemcpyHostToDevice));
+  M.built = true;
+  M.guarded.assign(1, 0xFFFFFFFFu);  // (no key: the first refresh writes the guard state, empty or not)
+  return refresh_linear_meshes(s);
+}
+
 int check_args(const ctr_scene *s, int bounces) {
   if (!s) return fail(CTR_E_INVALID, "null scene");
   if (bounces < 0 || bounces > CTR_MAX_BOUNCES)
@@ -647,12 +695,22 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     if (d->materials[i].type != CTR_MAT_PHONG)
       return fail(CTR_E_INVALID, "material #" + std::to_string(i) + ": bad type");
 
+  // CUTRACE_DEBUG_CREATE=1: where the call spends its time (stderr)
+  const bool dbg_t = getenv("CUTRACE_DEBUG_CREATE") != nullptr;
+  auto dbg_t0 = std::chrono::high_resolution_clock::now();
+  auto dbg_stamp = [&](const char *what) {
+    if (!dbg_t) return;
+    const auto now = std::chrono::high_resolution_clock::now();
+    fprintf(stderr, "cutrace_amd scene_create: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - dbg_t0).count());
+    dbg_t0 = now;
+  };
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) return fail(CTR_E_NO_DEVICE, "no HIP device available (and there is no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(CTR_E_INVALID, "device index out of range");
   HIP_TRY(hipSetDevice(device));
 
+  dbg_stamp("device check");
   // ---- flatten: per mesh a BVH + its triangles in leaf order (each keeps its file index for
   //      tie-breaks), stand-alone triangles appended ----
   std::vector<DObj> objs(d->n_objects);
@@ -754,6 +812,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         break;
     }
   }
+  dbg_stamp("meshes: BVH + records");
   std::vector<DObj> oloop, meshes_in, meshes;
   uint32_t n_axis_recs = 0;
   std::vector<DPlanePair> planes;
@@ -846,6 +905,8 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   // tree's records carry (mesh rank << 24 | file index) as their tie-break key — the reference's (object, triangle) order
   // as one integer — and the mesh's own AABB test (default_schema.hpp:99-114: a ray that fails it misses the mesh whatever
   // its triangles say) is applied afterwards, to the lanes the walk found something for.
+  // Built on demand (build_merged_tree, at the first ctr_set_variant with CTR_VAR_MERGE): here only its room in the device
+  // arrays is set aside and the triangles are kept.
   ctr_scene::Merged merged;
   std::vector<DObj> by_rank;  // non-empty meshes in scene order
   for (const DObj &O : objs)
@@ -854,51 +915,25 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     uint64_t total = 0;
     for (const DObj &O : by_rank) total += O.tri_count;
     if (by_rank.size() >= 2 && by_rank.size() <= CTR_MERGE_MAX_MESHES && total <= 0xFFFFFFull) {
-      std::vector<BvhInput> prims;
-      std::vector<std::pair<uint32_t, uint32_t>> who;  // (rank, file index) of prims[k]
-      prims.reserve(total);
-      who.reserve(total);
+      merged.reserved = true;
+      merged.src.reserve(total);
       for (uint32_t r = 0; r < by_rank.size(); r++) {
-        merged.slot_of.push_back((uint32_t)prims.size());
+        merged.slot_of.push_back((uint32_t)merged.src.size());
         const ctr_object &o = d->objects[by_rank[r].index];
-        const ctr_triangle *src = d->triangles + o.tri_begin;
-        for (uint32_t k = 0; k < (uint32_t)o.tri_count; k++) {
-          const ctr_vec3 *v[3] = {&src[k].p1, &src[k].p2, &src[k].p3};
-          BvhInput b;
-          for (int a = 0; a < 3; a++) {
-            const float c0 = (&v[0]->x)[a], c1 = (&v[1]->x)[a], c2 = (&v[2]->x)[a];
-            b.mn[a] = fminf(c0, fminf(c1, c2));
-            b.mx[a] = fmaxf(c0, fmaxf(c1, c2));
-            b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
-          }
-          prims.push_back(b);
-          who.push_back({r, k});
-        }
+        merged.src.insert(merged.src.end(), d->triangles + o.tri_begin, d->triangles + o.tri_begin + o.tri_count);
       }
-      std::vector<DNode4> mnodes;
-      std::vector<uint32_t> order;
-      bvh4_build(prims, BVH_LEAF, mnodes, order);
-      merged.built = true;
+      merged.slot_of.push_back((uint32_t)total);
       merged.tri_begin = (uint32_t)tris.size();
       merged.tri_count = (uint32_t)total;
       merged.node_begin = (uint32_t)nodes4.size();
-      merged.node_count = (uint32_t)mnodes.size();
-      nodes4.insert(nodes4.end(), mnodes.begin(), mnodes.end());
-      for (uint32_t k = 0; k < CTR_MERGED_SPARE_NODES; k++) {  // the spare nodes (guard records, refresh_linear_meshes)
-        nodes4.emplace_back();
-        memset(&nodes4.back(), 0, sizeof(DNode4));
-      }
-      tris.resize(tris.size() + total + CTR_GUARD_SLOTS);
+      merged.node_cap = (uint32_t)(total / 2 + 64);  // (a four-wide node has at least two children: far fewer in practice)
+      DNode4 zero4;
+      memset(&zero4, 0, sizeof(zero4));
+      nodes4.resize(nodes4.size() + merged.node_cap + CTR_MERGED_SPARE_NODES, zero4);
+      DTri zero_t;
+      memset(&zero_t, 0, sizeof(zero_t));
+      tris.resize(tris.size() + total + CTR_GUARD_SLOTS, zero_t);
       gn.resize(4 * tris.size());  // (unused for the merged records: normals are looked up in the mesh's own range)
-      merged.where.resize(total);
-      float dummy_gn[4];
-      for (uint32_t k = 0; k < (uint32_t)total; k++) {
-        const uint32_t r = who[order[k]].first, f = who[order[k]].second;
-        const ctr_triangle &t = d->triangles[d->objects[by_rank[r].index].tri_begin + f];
-        make_tri(t.p1, t.p2, t.p3, (r << 24) | f, tris[merged.tri_begin + k], dummy_gn);
-        merged.where[merged.slot_of[r] + f] = k;
-      }
-      for (uint32_t k = 0; k < CTR_GUARD_SLOTS; k++) tris[merged.tri_begin + total + k] = tris[merged.tri_begin];
       // the pseudo mesh record: the kernel's mesh code walks it like a mesh whose AABB every lane passes
       DObj P;
       memset(&P, 0, sizeof(P));
@@ -906,7 +941,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
       P.tri_begin = merged.tri_begin;
       P.tri_count = merged.tri_count;
       P.node_begin = merged.node_begin;
-      P.node_count = merged.node_count;
+      P.node_count = 0;
       P.bvh_root = 0;
       P.index = 0xFFFFFFFFu;
       for (int a = 0; a < 3; a++) { P.f[a] = tl_mn[a]; P.f[3 + a] = tl_mx[a]; }  // (margin of the box tests: the box of all meshes)
@@ -929,6 +964,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     if ((double)m.transparency >= 1e-6 || (double)m.reflexivity >= 1e-6) any_bounce = true;
   }
 
+  dbg_stamp("planes, top level, materials");
   auto *s = new ctr_scene();
   s->device = device;
   s->n_obj = (uint32_t)objs.size();
@@ -979,6 +1015,7 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     ctr_scene_destroy(s);
     return hip_fail(er, "scene upload");
   }
+  dbg_stamp("device allocation + upload");
   s->n_cams = 1;
   s->guards = std::move(guards);
   s->merged = std::move(merged);
@@ -990,10 +1027,12 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   s->h_cams.assign(1, s->cam);
   s->h_lights = lights;
   s->h_mats = mats;
+  dbg_stamp("host copies");
   if (int st = refresh_linear_meshes(s)) {
     ctr_scene_destroy(s);
     return st;
   }
+  dbg_stamp("guard records");
   *out = s;
   return CTR_OK;
 }
@@ -1064,6 +1103,12 @@ int ctr_set_variant(ctr_scene *s, uint32_t bits) {
                              CTR_VAR_NO_REORDER | CTR_VAR_NO_OCC6 | CTR_VAR_NO_DIRECT | CTR_VAR_IMAGE_ORDER_FIRST | CTR_VAR_MERGE;
   if (bits & ~KNOWN) return fail(CTR_E_INVALID, "ctr_set_variant: unknown variant bits " + std::to_string(bits & ~KNOWN));
   s->user_variant = bits;
+  if ((bits & CTR_VAR_MERGE) && s->merged.reserved && !s->merged.built) {
+    std::lock_guard<std::mutex> lk(s->mtx);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return build_merged_tree(s);
+  }
   return CTR_OK;
 }
 

@@ -51,7 +51,7 @@ class FrameTiler:
         self.part_stride = 1 if (rotate and world > 1 and frames > 1) else 0
         self.my_rows = part_rows(h, rank, world, block_rows) if world > 1 else list(range(h))
         self.cap = max_part_rows(h, world, block_rows) if world > 1 else h  # padded rows per rank
-        self.slots = slots if world > 1 else 1
+        self.slots = slots if (world > 1 or slots > 2) else 1   # (slots > 2: asked for explicitly — frames in flight on one GPU)
         self.rotate_roots = roots == "rotate" and world > 1 and frames > 1
         self.final_frames = [f for f in range(frames) if self.root_of(f) == rank]  # frames assembled on this rank
         f32 = torch.float32
@@ -140,7 +140,7 @@ class FrameTiler:
         if self.world == 1:
             F, h, w = self.frames, self.h, self.w
             d0, c0, n0, e = self.sec
-            buf = self.local[0]
+            buf = self.local[slot]
             self.final["depth"] = buf[d0:c0].view(F, h, w)
             self.final["color"] = buf[c0:n0].view(F, h, w, 3)
             self.final["normal"] = buf[n0:e].view(F, h, w, 3)

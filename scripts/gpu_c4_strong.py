@@ -10,16 +10,18 @@ path = scenes.make_bunny_grid(gen)
 
 def run(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scene", path, "--width", "4096", "--height", "4096",
-           "--scaling", "strong", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--skip-probe", "--no-extras"] + extra
+           "--scaling", "strong", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--skip-probe", "--no-extras"] + extra
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(r.stderr[-800:]); raise SystemExit(1)
     return json.loads(line[-1])
 
-full = run([])
-t1 = full["ms_per_step"]
-print(f"1 GPU: {t1:.3f} ms/frame, {full['value']:.0f} Mrays/s", flush=True)
-for n in (2, 4, 8):
-    ts = [run(["--of", str(n), "--as-rank", str(r)])["ms_per_step"] for r in range(n)]
-    print(f"{n} ranks: per-rank ms {[round(t, 3) for t in ts]}  -> balance-limited efficiency {t1 / (n * max(ts)):.3f}", flush=True)
+for label, extra in (("one launch after the other", []), ("two frames in flight (--in-flight 2)", ["--in-flight", "2"])):
+    print("#", label, flush=True)
+    full = run(extra)
+    t1 = full["ms_per_step"]
+    print(f"1 GPU: {t1:.3f} ms/frame, {full['value']:.0f} Mrays/s", flush=True)
+    for n in (2, 4, 8):
+        ts = [run(extra + ["--of", str(n), "--as-rank", str(r)])["ms_per_step"] for r in range(n)]
+        print(f"{n} ranks: per-rank ms {[round(t, 3) for t in ts]}  -> balance-limited efficiency {t1 / (n * max(ts)):.3f}", flush=True)
