@@ -26,6 +26,7 @@ VAR_NO_OCC6 = 512
 VAR_NO_DIRECT = 1024
 VAR_IMAGE_ORDER_FIRST = 2048
 VAR_MERGE = 4096
+VAR_IGNORE_TRANSPARENT = 8192
 
 
 @contextlib.contextmanager

@@ -392,7 +392,7 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
 #define CTR_GUARD_SLOTS 64u
 #define CTR_MERGED_SPARE_NODES ((CTR_GUARD_SLOTS + 2u) / 3u)  // the merged tree: three meshes' guard leaves per spare node
 #define CTR_MIRROR_MESH_TRIS 16u
-#define CTR_VIRTUAL_EYES_MAX 96u
+#define CTR_VIRTUAL_EYES_MAX 4096u  // (round 3: 96 — a 90-camera path through a room of five reflecting walls got images for its first 16 cameras only)
 int refresh_linear_meshes(ctr_scene *s) {
   constexpr double TOL = 1.0 / 131072.0;
   // ---- the points a family of rays can emanate from: eyes, and their images in the scene's flat mirrors ----
@@ -433,6 +433,12 @@ int refresh_linear_meshes(ctr_scene *s) {
     for (size_t e = 0; e < n_eyes && first.size() < CTR_VIRTUAL_EYES_MAX; e++)
       for (size_t m = 0; m < mirrors.size() && first.size() < CTR_VIRTUAL_EYES_MAX; m++) first.push_back({image(origins[e], mirrors[m]), m});
     for (const auto &f : first) origins.push_back(f.first);
+    if (n_eyes * mirrors.size() > first.size()) {
+      static bool warned = false;
+      if (!warned) fprintf(stderr, "cutrace_amd: %zu cameras x %zu flat mirrors exceed %u mirror images: the in-plane guard of reflected rays "
+                                   "(DESIGN.md section 2) covers the first %zu only\n", n_eyes, mirrors.size(), CTR_VIRTUAL_EYES_MAX, first.size());
+      warned = true;
+    }
     if (first.size() * (mirrors.size() ? mirrors.size() - 1 : 0) + origins.size() <= CTR_VIRTUAL_EYES_MAX)
       for (const auto &f : first)
         for (size_t m = 0; m < mirrors.size(); m++)
@@ -728,6 +734,10 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     O.type = o.type;
     O.mat = (uint32_t)o.mat_idx;
     O.index = (uint32_t)i;
+    {  // material::is_transparent (default_schema.hpp:334: `transparency >= 1e-6`, a double comparison): ray_cast's ignore_transparent
+      const uint32_t tr = ((double)d->materials[o.mat_idx].transparency >= 1e-6) ? 1u : 0u;
+      memcpy(&O.f[7], &tr, sizeof(tr));
+    }
     switch (o.type) {
       case CTR_OBJ_TRIANGLE: {
         O.tri_begin = (uint32_t)tris.size();
@@ -826,6 +836,10 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         if (!std::isfinite(O.f[a]) || !std::isfinite(O.f[3 + a])) finite = false;
         if (O.f[3 + a] != 0.0f) { nz++; axis = a; }
       }
+      // (and the point within 1e37: with the kernel's |origin| < 8.5e37 gate no component of point - origin overflows to
+      //  inf, which the reference would multiply by the normal's zero into a NaN — ADVICE r03)
+      for (int a = 0; a < 3; a++)
+        if (!(fabsf(O.f[a]) <= 1e37f)) finite = false;
       if (finite && nz == 1) axis_planes[axis].push_back(&O);
       else general_planes.push_back(&O);
     } else if (O.type == CTR_OBJ_MESH) { if (O.tri_count) meshes_in.push_back(O); }  // an empty mesh is never hit
@@ -836,12 +850,15 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
       DPlanePair pr;
       for (int a = 0; a < 3; a++) { pr.p[a][0] = pr.p[a][1] = 0.0f; pr.n[a][0] = pr.n[a][1] = 1.0f; }
       pr.index[0] = pr.index[1] = CTR_PLANE_PAD;
-      pr.pad[0] = pr.pad[1] = 0;
+      pr.transparent[0] = pr.transparent[1] = 0;
       return pr;
     };
     auto put = [](DPlanePair &pr, int slot, const DObj &O) {
       for (int a = 0; a < 3; a++) { pr.p[a][slot] = O.f[a]; pr.n[a][slot] = O.f[3 + a]; }
       pr.index[slot] = O.index;
+      uint32_t tr;
+      memcpy(&tr, &O.f[7], sizeof(tr));
+      pr.transparent[slot] = tr;
     };
     // fewer than three axis-aligned planes (a lone floor): one general record is less to fetch than a triple
     if (axis_planes[0].size() + axis_planes[1].size() + axis_planes[2].size() < 3) {
@@ -1100,7 +1117,7 @@ int ctr_scene_set_size(ctr_scene *s, uint64_t w, uint64_t h) {
 int ctr_set_variant(ctr_scene *s, uint32_t bits) {
   if (!s) return fail(CTR_E_INVALID, "null scene");
   constexpr uint32_t KNOWN = CTR_VAR_NO_PREFILTER | CTR_VAR_NO_ANYHIT | CTR_VAR_NO_CLUSTER | CTR_VAR_STATS | CTR_VAR_EXACT_POW |
-                             CTR_VAR_NO_REORDER | CTR_VAR_NO_OCC6 | CTR_VAR_NO_DIRECT | CTR_VAR_IMAGE_ORDER_FIRST | CTR_VAR_MERGE;
+                             CTR_VAR_NO_REORDER | CTR_VAR_NO_OCC6 | CTR_VAR_NO_DIRECT | CTR_VAR_IMAGE_ORDER_FIRST | CTR_VAR_MERGE | CTR_VAR_IGNORE_TRANSPARENT;
   if (bits & ~KNOWN) return fail(CTR_E_INVALID, "ctr_set_variant: unknown variant bits " + std::to_string(bits & ~KNOWN));
   s->user_variant = bits;
   if ((bits & CTR_VAR_MERGE) && s->merged.reserved && !s->merged.built) {
@@ -1118,6 +1135,7 @@ int ctr_render_device_batch(ctr_scene *s, float fudge, int bounces, const ctr_ro
   int st = check_args(s, bounces);
   if (st) return st;
   if (!d_depth || !d_color3 || !d_normal3) return fail(CTR_E_INVALID, "null output buffer");
+  if (s->user_variant & CTR_VAR_IGNORE_TRANSPARENT) return fail(CTR_E_INVALID, "CTR_VAR_IGNORE_TRANSPARENT: host-buffer calls only (ctr_render, ctr_render_uv)");
   if (n_frames == 0 || first_frame >= s->n_cams || n_frames > s->n_cams - first_frame)
     return fail(CTR_E_INVALID, "frame range exceeds the cameras set with ctr_scene_set_cameras");
   int cur = -1;
@@ -1182,7 +1200,7 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   // Any other destination: device buffers + copies, below.
   float *zd = nullptr, *zc = nullptr, *zn = nullptr;
   const bool merge_wanted = (s->user_variant & CTR_VAR_MERGE) && s->merged.built && s->merged.usable;  // (no delivering build of it)
-  const bool direct = px && depth && color3 && normal3 && !count && !uv2 && !(s->user_variant & (CTR_VAR_NO_DIRECT | CTR_VAR_STATS)) && !merge_wanted &&
+  const bool direct = px && depth && color3 && normal3 && !count && !uv2 && !(s->user_variant & (CTR_VAR_NO_DIRECT | CTR_VAR_STATS | CTR_VAR_IGNORE_TRANSPARENT)) && !merge_wanted &&
                       ctr_host_delivery_available(s->kernel_variant(false)) &&
                       is_pinned(depth) && is_pinned(depth + px - 1) && is_pinned(color3) && is_pinned(color3 + 3 * px - 1) &&
                       is_pinned(normal3) && is_pinned(normal3 + 3 * px - 1) && device_view(depth, &zd) &&
@@ -1216,8 +1234,9 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   }
   L.counters = s->d_counters;
   L.variant = s->kernel_variant(count);
-  if (uv2 && px) {
-    if (count || (s->user_variant & CTR_VAR_STATS)) return fail(CTR_E_INVALID, "ctr_render_uv: not with the counting / statistics variants");
+  const bool igntr = (s->user_variant & CTR_VAR_IGNORE_TRANSPARENT) != 0 && !count;
+  if ((uv2 || igntr) && px) {
+    if (count || (s->user_variant & CTR_VAR_STATS)) return fail(CTR_E_INVALID, "ctr_render_uv / CTR_VAR_IGNORE_TRANSPARENT: not with the counting / statistics variants");
     if (px > s->uv_px) {
       if (s->d_uv) (void)hipFree(s->d_uv);
       s->d_uv = nullptr;
@@ -1226,7 +1245,7 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
       s->uv_px = px;
     }
     L.uv = s->d_uv;
-    L.variant = (L.variant & (KV_ANYHIT | KV_FASTPOW)) | KV_PREFILTER | KV_BVH | KV_UV;
+    L.variant = (L.variant & (KV_ANYHIT | KV_FASTPOW)) | KV_PREFILTER | KV_BVH | KV_UV | (igntr ? KV_IGNTR : 0u);
   }
   use_merged_tree(s, L);
   if ((st = attach_order(s, L, count))) return st;
@@ -1261,12 +1280,10 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
   HIP_TRY(hipStreamSynchronize(nullptr));
   if (direct) {
     // every group of tiles must have counted all its tiles, or its pixels never left for the caller's buffers
-    const uint32_t tiles_x = (s->cam.w + 7) / 8, groups_x = (tiles_x + 7) / 8;
+    // (how many tiles a group has is the kernel's business — its tile shape is a build option: ctr_group_tile_count)
     size_t missing = 0;
-    for (size_t g = 0; g < n_groups; g++) {
-      const uint32_t gx = (uint32_t)(g % groups_x), nt = tiles_x - gx * 8 < 8 ? tiles_x - gx * 8 : 8;
-      if (s->h_groups[g] != nt) missing++;
-    }
+    for (size_t g = 0; g < n_groups; g++)
+      if (s->h_groups[g] != ctr_group_tile_count(L, g)) missing++;
     if (missing) {
       s->order_valid = false;  // whatever order that launch ran in is not to be trusted
       return fail(CTR_E_DELIVERY, std::to_string(missing) + " of " + std::to_string(n_groups) +
@@ -1279,11 +1296,11 @@ static int render_host(ctr_scene *s, float fudge, int bounces, const ctr_rows *r
     // and compare every pixel with what arrived in the caller's buffers.
     std::vector<float> stg(7 * spx);
     HIP_TRY(hipMemcpy(stg.data(), s->d_out, sizeof(float) * 7 * spx, hipMemcpyDeviceToHost));
-    const uint32_t w = s->cam.w, tiles_x = (w + 7) / 8;
+    const uint32_t w = s->cam.w;
     uint64_t bad = 0;
     for (uint32_t y = 0; y < L.rows.n_rows; y++)
       for (uint32_t x = 0; x < w; x++) {
-        const size_t at = (size_t)y * w + x, sp = ((size_t)(y / 8) * tiles_x + x / 8) * 64 + (y % 8) * 8 + x % 8;
+        const size_t at = (size_t)y * w + x, sp = (size_t)ctr_staging_index(L, x, y);
         bool ok = memcmp(&depth[at], &stg[sp], 4) == 0;
         ok = ok && memcmp(&color3[3 * at], &stg[spx + 3 * sp], 12) == 0 && memcmp(&normal3[3 * at], &stg[4 * spx + 3 * sp], 12) == 0;
         bad += ok ? 0 : 1;

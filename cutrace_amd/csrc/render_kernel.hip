@@ -374,6 +374,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   constexpr bool FASTPOW = (KV & KV_FASTPOW) != 0;
   constexpr bool HOSTOUT = (KV & KV_HOSTOUT) != 0;  // "Host delivery"
   constexpr bool UV = (KV & KV_UV) != 0;            // ray_cast's tex_coords of the primary cast as a fourth output
+  // ray_cast's ninth argument (ray_cast.hpp:30,39-40: `if (ignore_transparent && is_transparent(mat)) continue;`).  Every caller
+  // of the reference passes false; with IGNTR the cast of kernel.hpp:52 — the one depth, normal and tex_coords come from — is
+  // made with true, as a trip of its own before ray_color's first cast (shading.hpp:123, false), which it otherwise shares
+  constexpr bool IGNTR = (KV & KV_IGNTR) != 0;
   constexpr bool MERGE = (KV & KV_MERGE) != 0;      // "merged walk": the top-level item may be the pseudo mesh over all meshes' triangles
   static_assert(!MERGE || BVH, "the merged tree is a BVH walk");
   // wave-level work counters (STATS build only): [0] casts, [1] BVH nodes visited, [2] triangle
@@ -506,7 +510,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
   uint32_t mat_i = 0, li = 0;
   V3 out_rgb = mk(0, 0, 0);
   // casts of the whole wave, counted on the scalar unit; the duplicated primary cast (kernel.hpp:52) counts too
-  unsigned long long n_casts = (unsigned long long)__builtin_popcountll(BALLOT(in_image));
+  // (IGNTR: the kernel.hpp:52 cast is a trip of its own and is counted there)
+  unsigned long long n_casts = IGNTR ? 0ull : (unsigned long long)__builtin_popcountll(BALLOT(in_image));
   unsigned long long n_aabb_tris = 0;
 
   // Cold kernel arguments — what only the continuation needs (hit records, lights, materials) — are read from
@@ -581,6 +586,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     TACC(0, t_trip0, t_loop0);
     CTR_MARK(3);  // planes: set-up
     const bool anyhit_cast = ANYHIT && shadow_cast;
+    const bool ign_now = IGNTR && first_trip;  // wave-uniform: this trip is the kernel.hpp:52 cast with ignore_transparent = true
     // ---- planes: plane::intersect, default_schema.hpp:189-201, all in lane masks ----
     {
       mask_t live_m = alive_m;
@@ -653,7 +659,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       if (n_axis != 0u && A.fudge >= 1e-30f) {
         CTR_MARK(4);
         // NaN iff some component is not finite (or the sum overflows: then the general code, which is always right)
-        const float chk = (((((ro.x + ro.y) + ro.z) + rd.x) + rd.y) + rd.z) * 0.0f;
+        // (the origin's components times 4: beyond 8.5e37 the product is inf, so the differences point - origin of the
+        //  planes — whose points the upload bounds by 1e37 — cannot overflow either: an infinite difference times the normal's
+        //  zero is a NaN in the reference, a miss, where the one-product form would report a hit)
+        const float chk = __builtin_fmaf(ro.x, 4.0f, __builtin_fmaf(ro.y, 4.0f, __builtin_fmaf(ro.z, 4.0f, (rd.x + rd.y) + rd.z))) * 0.0f;
         axis_fast = (alive_m & ~FCMP(chk, 0.0f, FC_OEQ)) == 0ull;
       }
       for (uint32_t p = 0; p < n_recs;) {
@@ -677,12 +686,13 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           }
           p += 3;
           // (a slot without a plane: CTR_PLANE_PAD)
-          if (i00 != CTR_PLANE_PAD) { if (!plane_test(i00, num0.x, den0.x, SITE(0))) break; }
-          if (i01 != CTR_PLANE_PAD) { if (!plane_test(i01, num0.y, den0.y, SITE(1))) break; }
-          if (i10 != CTR_PLANE_PAD) { if (!plane_test(i10, num1.x, den1.x, SITE(2))) break; }
-          if (i11 != CTR_PLANE_PAD) { if (!plane_test(i11, num1.y, den1.y, SITE(3))) break; }
-          if (i20 != CTR_PLANE_PAD) { if (!plane_test(i20, num2.x, den2.x, SITE(4))) break; }
-          if (i21 != CTR_PLANE_PAD) { if (!plane_test(i21, num2.y, den2.y, SITE(5))) break; }
+          // (a slot without a plane: CTR_PLANE_PAD; IGNTR: a plane whose material is transparent does not exist for this cast)
+          if (i00 != CTR_PLANE_PAD && !(IGNTR && ign_now && P0.transparent[0])) { if (!plane_test(i00, num0.x, den0.x, SITE(0))) break; }
+          if (i01 != CTR_PLANE_PAD && !(IGNTR && ign_now && P0.transparent[1])) { if (!plane_test(i01, num0.y, den0.y, SITE(1))) break; }
+          if (i10 != CTR_PLANE_PAD && !(IGNTR && ign_now && P1.transparent[0])) { if (!plane_test(i10, num1.x, den1.x, SITE(2))) break; }
+          if (i11 != CTR_PLANE_PAD && !(IGNTR && ign_now && P1.transparent[1])) { if (!plane_test(i11, num1.y, den1.y, SITE(3))) break; }
+          if (i20 != CTR_PLANE_PAD && !(IGNTR && ign_now && P2.transparent[0])) { if (!plane_test(i20, num2.x, den2.x, SITE(4))) break; }
+          if (i21 != CTR_PLANE_PAD && !(IGNTR && ign_now && P2.transparent[1])) { if (!plane_test(i21, num2.y, den2.y, SITE(5))) break; }
         } else {
           const CADDR DPlanePair &P0 = k_planes[p];
           CTR_MARK(7);  // one plane record
@@ -690,8 +700,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           num_den(P0, num0, den0);
           const uint32_t i00 = P0.index[0], i01 = P0.index[1];
           p += 1;
-          if (!plane_test(i00, num0.x, den0.x, SITE(6))) break;
-          if (i01 != CTR_PLANE_PAD) {
+          if (!(IGNTR && ign_now && P0.transparent[0])) { if (!plane_test(i00, num0.x, den0.x, SITE(6))) break; }
+          if (i01 != CTR_PLANE_PAD && !(IGNTR && ign_now && P0.transparent[1])) {
             if (!plane_test(i01, num0.y, den0.y, SITE(7))) break;
           }
         }
@@ -714,6 +724,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       const CADDR DObj &O = AK->oloop[oi];
       const uint32_t i = O.index;
       const uint32_t type = O.type;
+      if (IGNTR && ign_now && __float_as_uint(O.f[7]) != 0u) continue;  // ray_cast.hpp:40
       CTR_MARK(9);  // a sphere or stand-alone triangle
       bool ok = false;
       float cand = INFINITY;
@@ -903,6 +914,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         } else {
           t_pend = TL_NONE;
         }
+        if (IGNTR && ign_now && __float_as_uint(O.f[7]) != 0u) continue;  // ray_cast.hpp:40: a mesh with a transparent material
         CTR_MARK(17);  // a mesh: AABB test
         const uint32_t i = O.index;
         // (the whole record in one round trip: what the walk needs is requested with the box, not after its test)
@@ -1410,6 +1422,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     uint32_t nl_type = 0u;
     V3 nl_v = mk(0.f, 0.f, 0.f);
     if (MSP_IS_RADIANCE(msp)) {
+      const V3 ro_keep = ro;  // (IGNTR: the primary ray is cast once more, for ray_color)
       // ---- hit record: hit point, normal (per primitive), material ----
       V3 normal = mk(0, 0, 0);
       float tc_u = 0.0f, tc_v = 0.0f;  // (UV) uv{} of kernel.hpp:51 on a miss
@@ -1485,7 +1498,11 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
         first_depth = best;
       }
       CTR_MARK(41);
-      if (!was_hit) {
+      if (IGNTR && ign_now) {
+        // that was the cast of kernel.hpp:52; now ray_color's own first cast (shading.hpp:123, ignore_transparent = false) of the same ray
+        ro = ro_keep;
+        min_t = A.fudge;
+      } else if (!was_hit) {
         out_rgb = mk(0.f, 0.f, 0.f);  // shading.hpp:119
         act = ACT_UNWIND;
       } else {
@@ -2194,6 +2211,16 @@ uint64_t ctr_staging_groups(const RenderLaunch &L) {
   return ((tiles_x + GROUP_TILES - 1) / GROUP_TILES) * tiles_y;
 }
 
+uint32_t ctr_group_tile_count(const RenderLaunch &L, uint64_t group) {
+  const uint32_t tiles_x = (L.w + TW - 1) / TW, groups_x = (tiles_x + GROUP_TILES - 1) / GROUP_TILES;
+  const uint32_t gx = (uint32_t)(group % groups_x);
+  return tiles_x - gx * GROUP_TILES < GROUP_TILES ? tiles_x - gx * GROUP_TILES : GROUP_TILES;
+}
+uint64_t ctr_staging_index(const RenderLaunch &L, uint32_t x, uint32_t k_row) {
+  const uint64_t tiles_x = (L.w + TW - 1) / TW;
+  return ((uint64_t)(k_row / TH) * tiles_x + x / TW) * 64u + (k_row % TH) * TW + x % TW;
+}
+
 // The 6-waves-per-SIMD build parks 1280 bytes of shading state per wave in LDS (render_kernel PARK); LDS is handed out
 // in granules of 1280 bytes (160 KB / 128), and 24 waves per CU need at most 5 granules each
 static bool occ6_fits(size_t stack_bytes) { return (stack_bytes + 1280u + 1279u) / 1280u <= 5u; }
@@ -2213,6 +2240,11 @@ int ctr_launch_render(const RenderLaunch &L, void *stream) {
     if (!(L.variant & KV_ANYHIT)) return launch<DEF>(L, s);
     if ((L.variant & KV_OCC6) && occ6_fits(sb)) return launch<DEF | KV_ANYHIT | KV_OCC6>(L, s);
     return launch<DEF | KV_ANYHIT>(L, s);
+  }
+  if ((L.variant & (KV_UV | KV_IGNTR)) == (KV_UV | KV_IGNTR)) {  // ... with the kernel.hpp:52 cast ignoring transparent objects
+    constexpr uint32_t U = KV_PREFILTER | KV_BVH | KV_UV | KV_IGNTR;
+    if (L.variant & KV_FASTPOW) return (L.variant & KV_ANYHIT) ? launch<U | KV_FASTPOW | KV_ANYHIT>(L, s) : launch<U | KV_FASTPOW>(L, s);
+    return (L.variant & KV_ANYHIT) ? launch<U | KV_ANYHIT>(L, s) : launch<U>(L, s);
   }
   if (L.variant & KV_UV) {  // the fourth output: the shipped walk only (BVH + prefilter), any-hit and pow as the scene / caller say
     constexpr uint32_t U = KV_PREFILTER | KV_BVH | KV_UV;

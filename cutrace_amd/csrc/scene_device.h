@@ -58,6 +58,7 @@ struct DObj {
   // mesh    : f[0..2] bbox.min, f[3..5] bbox.max
   // plane   : f[0..2] point,    f[3..5] normal
   // sphere  : f[0..2] center,   f[3] radius, f[4] radius*radius
+  // all     : f[7] (as bits) 1 when the object's material is transparent (ray_cast's ignore_transparent, KV_IGNTR only)
   float f[8];
 };
 static_assert(sizeof(DObj) == 64, "DObj must be 64 bytes");
@@ -78,7 +79,8 @@ struct DPlanePair {
   float p[3][2];        // point:  p[axis][which plane]
   float n[3][2];        // normal
   uint32_t index[2];    // position in the scene's object list
-  uint32_t pad[2];
+  uint32_t transparent[2];  // 1: the plane's material is transparent (material::is_transparent, default_schema.hpp:334): what
+                            // ray_cast's ignore_transparent skips (ray_cast.hpp:39-40; KV_IGNTR only)
 };
 static_assert(sizeof(DPlanePair) == 64, "DPlanePair must be 64 bytes");
 #define CTR_PLANE_PAD 0xFFFFFFFFu
@@ -115,6 +117,7 @@ enum : uint32_t {
   KV_OCC6 = 64u,       // compiled for 6 waves per SIMD instead of 5 (large meshes: latency-bound on scalar-cache misses)
   KV_HOSTOUT = 128u,   // the launch delivers the frame to page-locked host memory itself (RenderLaunch::group_done)
   KV_UV = 256u,        // also write the texture coordinates of the primary hit (ray_cast's tex_coords), RenderLaunch::uv
+  KV_IGNTR = 1024u,    // the cast of kernel.hpp:52 (depth, normal, uv) is made with ray_cast's ignore_transparent = true (CTR_VAR_IGNORE_TRANSPARENT)
   KV_MERGE = 512u,     // the walk may meet the merged pseudo mesh: ONE tree over the triangles of all meshes (CTR_VAR_MERGE)
 };
 
@@ -177,6 +180,8 @@ struct RenderLaunch {
 };
 uint64_t ctr_staging_pixels(const RenderLaunch &L);
 uint64_t ctr_staging_groups(const RenderLaunch &L);
+uint32_t ctr_group_tile_count(const RenderLaunch &L, uint64_t group);          // tiles group `group` counts when it is complete
+uint64_t ctr_staging_index(const RenderLaunch &L, uint32_t x, uint32_t k_row); // staging pixel of compact pixel (x, k_row)
 bool ctr_host_delivery_available(uint32_t kernel_variant);
 
 // keeps `msg` for ctr_last_error() (ctr_api.cpp); used by the other translation units of the library

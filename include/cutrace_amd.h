@@ -266,6 +266,10 @@ int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
 #define CTR_VAR_NO_DIRECT 1024u   /* ctr_render / ctr_render_multi: page-locked destinations get device buffers + DMA instead of delivery by the kernels */
 #define CTR_VAR_MERGE 4096u       /* scenes with 2..255 meshes: walk ONE tree over the triangles of all meshes instead of a tree over the meshes' boxes and
                                    * then each mesh's own tree.  Same results; measured SLOWER on every shipped config (profiles/r04/exp_merged_tree_ab.txt), so opt-in */
+#define CTR_VAR_IGNORE_TRANSPARENT 8192u /* ctr_render / ctr_render_uv: the cast of kernel.hpp:52 — the one depth, normal (and uv) come from — is made with
+                                   * ray_cast's ignore_transparent = true (inc/ray_cast.hpp:30,39-40): objects whose material is transparent
+                                   * (transparency >= 1e-6, default_schema.hpp:334) do not exist for it.  Colour is unchanged: ray_color's own casts
+                                   * pass false (shading.hpp:32,123).  No caller of the reference passes true; this is the branch, restated. */
 #define CTR_VAR_NO_OCC6 512u      /* never pick the build compiled for 6 waves per SIMD (chosen for scenes with >= 1000 mesh triangles) */
 /* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
  * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles

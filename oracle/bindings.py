@@ -12,9 +12,9 @@ _oracle = None
 _ref = None
 
 
-def _render_sig(fn, uv=False):
+def _render_sig(fn, uv=False, ex=False):
     fn.argtypes = [C.POINTER(_lib.SceneDesc), C.c_float, C.c_int, C.POINTER(_lib.Rows), C.c_int, C.c_void_p,
-                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + ([C.c_void_p] if uv else [])
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + ([C.c_void_p] if (uv or ex) else []) + ([C.c_int] if ex else [])
     fn.restype = C.c_int
 
 
@@ -27,6 +27,7 @@ def oracle_lib():
         L = C.CDLL(path)
         _render_sig(L.orc_render)
         _render_sig(L.orc_render_uv, uv=True)
+        _render_sig(L.orc_render_ex, ex=True)
         L.orc_look_at.argtypes = [C.POINTER(_lib.Camera), _lib.Vec3, _lib.Vec3, _lib.Vec3]
         L.orc_quantise_depth.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
         L.orc_quantise_normal.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
@@ -47,6 +48,8 @@ def ref_lib():
         _render_sig(L.ref_render)
         if hasattr(L, "ref_render_uv"):
             _render_sig(L.ref_render_uv, uv=True)
+        if hasattr(L, "ref_render_ex"):
+            _render_sig(L.ref_render_ex, ex=True)
         L.ref_look_at.argtypes = [C.POINTER(_lib.Camera), _lib.Vec3, _lib.Vec3, _lib.Vec3]
         _ref = L
     return _ref
@@ -100,7 +103,7 @@ def ref_fmad_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=
     return _cpu_render(L.ref_render, scene, fudge, bounces, rows, threads, hit_ids)
 
 
-def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids, want_uv=False):
+def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids, want_uv=False, ignore_transparent=None):
     w, h = scene.size
     r = make_rows(h, rows)
     n = rows_count(h, rows)
@@ -112,8 +115,10 @@ def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids, want_uv=
     uv = np.empty((n, w, 2), np.float32) if want_uv else None
     args = [scene.desc, C.c_float(fudge), bounces, C.byref(r), threads, depth.ctypes.data, color.ctypes.data,
             normal.ctypes.data, hit.ctypes.data if hit is not None else None, counters]
-    if want_uv:
-        args.append(uv.ctypes.data)
+    if want_uv or ignore_transparent is not None:
+        args.append(uv.ctypes.data if uv is not None else None)
+    if ignore_transparent is not None:   # the *_render_ex entry points
+        args.append(1 if ignore_transparent else 0)
     st = fn(*args)
     if st:
         raise RuntimeError(f"cpu render failed: {st}")
@@ -121,15 +126,20 @@ def _cpu_render(fn, scene, fudge, bounces, rows, threads, want_hit_ids, want_uv=
                 alg_bytes=int(counters[1]), uv=uv)
 
 
-def oracle_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True, uv=False):
-    """CPU restatement (oracle/ctr_oracle.c).  uv=True: also the texture coordinates of the primary hit."""
+def oracle_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True, uv=False, ignore_transparent_primary=False):
+    """CPU restatement (oracle/ctr_oracle.c).  uv=True: also the texture coordinates of the primary hit.
+    ignore_transparent_primary: the kernel.hpp:52 cast with ray_cast's ignore_transparent = true (ray_cast.hpp:39-40)."""
     L = oracle_lib()
+    if ignore_transparent_primary:
+        return _cpu_render(L.orc_render_ex, scene, fudge, bounces, rows, threads, hit_ids, uv, True)
     return _cpu_render(L.orc_render_uv if uv else L.orc_render, scene, fudge, bounces, rows, threads, hit_ids, uv)
 
 
-def ref_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True, uv=False):
+def ref_render(scene, fudge=1e-3, bounces=5, rows=None, threads=1, hit_ids=True, uv=False, ignore_transparent_primary=False):
     """The reference's own headers compiled for the host (oracle/_ref)."""
     L = ref_lib()
     if L is None:
         raise RuntimeError("oracle/_ref/libcutrace_ref.so not built (needs /root/reference)")
+    if ignore_transparent_primary:
+        return _cpu_render(L.ref_render_ex, scene, fudge, bounces, rows, threads, hit_ids, uv, True)
     return _cpu_render(L.ref_render_uv if uv else L.ref_render, scene, fudge, bounces, rows, threads, hit_ids, uv)

@@ -75,6 +75,7 @@ typedef struct {
   int trace;            /* debugging aid: print every cast (orc_trace_pixel) */
   int64_t last_tri;     /* index (within the mesh) of the triangle that won the last mesh_intersect */
   float *uv;            /* optional output: texture coordinates of the primary hit, 2 floats per pixel */
+  int ignore_transparent_primary; /* the kernel.hpp:52 cast is made with ignore_transparent = true (orc_render_ex) */
 } octx;
 
 /* ---- inc/default_schema.hpp primitives ------------------------------------ */
@@ -172,7 +173,7 @@ static int obj_intersect(octx *cx, const ctr_object *o, const ray *r, float min_
 }
 
 /* ---- inc/ray_cast.hpp:29-55 ------------------------------------------------ */
-static int ray_cast(octx *cx, const ray *finder, float min_dist, float *distance, uint64_t *hit_id, vec *hit_point, vec *normal) {
+static int ray_cast(octx *cx, const ray *finder, float min_dist, float *distance, uint64_t *hit_id, vec *hit_point, vec *normal, int ignore_transparent) {
   const ctr_scene_desc *s = cx->s;
   cx->casts++;
   cx->alg_bytes += 56ull * s->n_objects;
@@ -181,7 +182,9 @@ static int ray_cast(octx *cx, const ray *finder, float min_dist, float *distance
   float dist;
   int was_hit = 0;
   for (uint64_t i = 0; i < s->n_objects; i++) {
-    /* ray_cast.hpp:39-40: ignore_transparent is false at every call site */
+    /* ray_cast.hpp:39-40 (false at every call site of the reference; orc_render_ex can make the kernel.hpp:52 cast with
+     * true): material::is_transparent, default_schema.hpp:334 — `transparency >= 1e-6`, a double comparison */
+    if (ignore_transparent && (double)s->materials[s->objects[i].mat_idx].transparency >= 1e-6) continue;
     if (obj_intersect(cx, &s->objects[i], finder, min_dist, &hit, &dist, &nrm)) {
       if (dist > min_dist && dist < *distance) {
         *distance = dist;
@@ -211,7 +214,7 @@ static float shadow_intensity(octx *cx, const ray *shadow_ray, float max_dist) {
   uint64_t h = 0;
   vec hit = {0, 0, 0}, normal = {0, 0, 0};
   /* shading.hpp:32: `last_hit + 1e-3` is a DOUBLE add narrowed to float at the call */
-  while (ray_cast(cx, &check, (float)((double)last_hit + 1e-3), &dist, &h, &hit, &normal) && dist < max_dist) {
+  while (ray_cast(cx, &check, (float)((double)last_hit + 1e-3), &dist, &h, &hit, &normal, 0) && dist < max_dist) {
     float trans = s->materials[s->objects[h].mat_idx].transparency; /* get_bounce_params, default_schema.hpp:337-340 */
     intensity += (1.0f - trans);
     if (intensity >= 1.0f) return 1.0f;
@@ -264,7 +267,7 @@ static vec ray_color(octx *cx, const ray *incoming, float min_t, float ambient, 
   uint64_t id = 0;
   vec normal = {0, 0, 0}, rgb = {0.0f, 0.0f, 0.0f}, hit = {0, 0, 0};
   float distance;
-  if (ray_cast(cx, incoming, min_t, &distance, &id, &hit, &normal)) {
+  if (ray_cast(cx, incoming, min_t, &distance, &id, &hit, &normal, 0)) {
     rgb = phong(cx, incoming, &hit, id, &normal, ambient);
     if (bounces != 0) {
       const ctr_material *m = &s->materials[s->objects[id].mat_idx];
@@ -337,7 +340,7 @@ static void render_pixel(octx *cx, uint64_t x_id, uint64_t y_id, float fudge, in
   ray r = cam_get_ray(&s->cam, x_id, y_id);
   uint64_t hit_id = s->n_objects;
   vec hit_point = {0, 0, 0}, normal = {0, 0, 0};
-  int did_hit = ray_cast(cx, &r, fudge, &dist, &hit_id, &hit_point, &normal);
+  int did_hit = ray_cast(cx, &r, fudge, &dist, &hit_id, &hit_point, &normal, cx->ignore_transparent_primary);
   depth[out_idx] = dist;
   normals[out_idx] = normal;
   if (hit_ids) hit_ids[out_idx] = did_hit ? (int64_t)hit_id : -1;
@@ -363,11 +366,12 @@ typedef struct {
   uint64_t *next;        /* shared atomic row counter */
   uint64_t casts, alg_bytes;
   float *uv;
+  int ign;
 } job;
 
 static void *worker(void *arg) {
   job *j = (job *)arg;
-  octx cx = {j->s, 0, 0, 0, -1, j->uv};
+  octx cx = {j->s, 0, 0, 0, -1, j->uv, j->ign};
   uint64_t w = j->s->cam.w;
   for (;;) {
     uint64_t k = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
@@ -398,8 +402,18 @@ int orc_render(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows
 }
 
 /* ... plus uv2 (optional): texture coordinates of the primary hit, 2 floats per pixel (0, 0 on a miss) */
+int orc_render_ex(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
+                  float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2, int ignore_transparent_primary);
 int orc_render_uv(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
                   float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2) {
+  return orc_render_ex(s, fudge, bounces, rows_in, n_threads, depth, color3, normal3, hit_ids, counters, uv2, 0);
+}
+
+/* ... plus ignore_transparent_primary: the cast of kernel.hpp:52 (depth, normal, hit id, uv) is made with ray_cast's
+ * ignore_transparent = true (ray_cast.hpp:30,39-40) — objects whose material is transparent do not exist for it; ray_color's
+ * own casts stay as the reference's shading code makes them (shading.hpp:32,123 pass false) */
+int orc_render_ex(const ctr_scene_desc *s, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
+                  float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2, int ignore_transparent_primary) {
   ctr_rows rr = {0, s->cam.h, s->cam.h ? s->cam.h : 1, 0, 1};
   if (rows_in && rows_in->row_end > rows_in->row_begin) {
     rr = *rows_in;
@@ -416,7 +430,7 @@ int orc_render_uv(const ctr_scene_desc *s, float fudge, int bounces, const ctr_r
   job *jobs = (job *)calloc((size_t)n_threads, sizeof(job));
   pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
   for (int t = 0; t < n_threads; t++) {
-    job jj = {s, fudge, bounces, sel, n, depth, (vec *)color3, (vec *)normal3, hit_ids, &next, 0, 0, uv2};
+    job jj = {s, fudge, bounces, sel, n, depth, (vec *)color3, (vec *)normal3, hit_ids, &next, 0, 0, uv2, ignore_transparent_primary};
     jobs[t] = jj;
   }
   if (n_threads == 1) worker(&jobs[0]);

@@ -169,8 +169,17 @@ int ref_render(const ctr_scene_desc *d, float fudge, int bounces, const ctr_rows
   return ref_render_uv(d, fudge, bounces, rows_in, n_threads, depth, color3, normal3, hit_ids, counters, nullptr);
 }
 
+int ref_render_ex(const ctr_scene_desc *d, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
+                  float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2, int ignore_transparent_primary);
 int ref_render_uv(const ctr_scene_desc *d, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
                   float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2) {
+  return ref_render_ex(d, fudge, bounces, rows_in, n_threads, depth, color3, normal3, hit_ids, counters, uv2, 0);
+}
+
+// ... plus ignore_transparent_primary: the ninth argument of the reference's ray_cast (inc/ray_cast.hpp:30,39-40) for the cast
+// of kernel.hpp:52; no caller of the reference passes true, this harness can
+int ref_render_ex(const ctr_scene_desc *d, float fudge, int bounces, const ctr_rows *rows_in, int n_threads,
+                  float *depth, float *color3, float *normal3, int64_t *hit_ids, uint64_t *counters, float *uv2, int ignore_transparent_primary) {
   built_scene b;
   build(d, b, counters != nullptr);
   const scene_t *scene = &b.scene;
@@ -204,7 +213,7 @@ int ref_render_uv(const ctr_scene_desc *d, float fudge, int bounces, const ctr_r
         size_t hit_id = scene->objects.size;
         vector hit_point{}, normal{0, 0, 0};
         cutrace::uv tc{};
-        bool did_hit = cutrace::gpu::ray_cast(scene, &r, fudge, &dist, &hit_id, &hit_point, &normal, &tc, false);
+        bool did_hit = cutrace::gpu::ray_cast(scene, &r, fudge, &dist, &hit_id, &hit_point, &normal, &tc, ignore_transparent_primary != 0);
         size_t px = k * w + x_id;
         depth[px] = dist;
         normal3[3 * px + 0] = normal.x; normal3[3 * px + 1] = normal.y; normal3[3 * px + 2] = normal.z;

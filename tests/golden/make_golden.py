@@ -60,6 +60,15 @@ def main():
         path = os.path.join(OUT, f"uv_{name}_{w}x{h}.npz")
         np.savez_compressed(path, uv=r["uv"], hit_id=r["hit_id"].astype(np.int32), depth=r["depth"])
         print("wrote", path)
+    # the kernel.hpp:52 cast with ray_cast's ignore_transparent = true (ray_cast.hpp:30,39-40; no caller of the reference
+    # passes true, the harness can): sphere_plane.json has a transparent sphere (scene/sphere_plane.json:26)
+    s = ca.HostScene.load("scene/sphere_plane.json")
+    s.set_size(96, 54)
+    r = oracle.ref_render(s, bounces=5, threads=THREADS, uv=True, ignore_transparent_primary=True)
+    path = os.path.join(OUT, "ignore_transparent_sphere_plane_96x54_b5.npz")
+    np.savez_compressed(path, depth=r["depth"], color=r["color"], normal=r["normal"], uv=r["uv"], hit_id=r["hit_id"].astype(np.int32),
+                        ray_count=np.int64(r["ray_count"]))
+    print("wrote", path)
     if "--uv-only" in sys.argv:
         return
     only_small = "--small" in sys.argv

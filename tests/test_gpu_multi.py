@@ -388,3 +388,22 @@ def test_pipelined_submit_wait_over_the_rccl_branch(ca):
             for f in frames:
                 m.free_frame(f)
     m.close()
+
+
+def test_bench_two_steps_in_flight_two_ranks(ca):
+    """bench.py --in-flight 2 (consecutive steps alternate between two scene handles on two streams, so the next step's first
+    waves fill the tail of the previous one) with two ranks on the one GPU (gloo): four buffer slots per rank, exchanges of
+    two steps outstanding — every gathered frame still bitwise the single-process render."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CUTRACE_BENCH_SHARE_GPU="1", CUTRACE_BENCH_BACKEND="gloo")
+    for extra in (["--width", "640", "--height", "360"],
+                  ["--workload", "c4", "--scaling", "strong", "--roots", "rank0", "--width", "512", "--height", "512"]):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--in-flight", "2",
+               "--check", "--no-extras", "--skip-probe"] + extra
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "gathered frame(s) bitwise equal" in r.stderr
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["config"]["steps_in_flight"] == 2

@@ -832,3 +832,36 @@ def test_axis_aligned_planes(gpu, case):
     assert s.ok, s.error
     fudge = {"fudge_zero": 0.0, "fudge_negative": -0.25}.get(case, 1e-3)
     _check_all_ways(gpu, s, f"axis-aligned planes: {case}", bounces=3, fudge=fudge)
+
+
+def test_ignore_transparent_primary_cast(ca):
+    """CTR_VAR_IGNORE_TRANSPARENT: the cast of kernel.hpp:52 made with ray_cast's ignore_transparent = true
+    (inc/ray_cast.hpp:30,39-40).  Depth, normal and texture coordinates then come from a scene without its transparent
+    objects; the colour is that of the plain render (ray_color's own casts pass false).  Against the reference-build fixture,
+    the oracle on random scenes (every object type with transparent materials), and the ray count (unchanged)."""
+    g = np.load(os.path.join(GOLD, "ignore_transparent_sphere_plane_96x54_b5.npz"))
+    s = load_scene(ca, "sphere_plane", 96, 54)
+    ds = ca.DeviceScene(s)
+    plain = ds.render(bounces=5)
+    ds.set_variant(ca.VAR_IGNORE_TRANSPARENT)
+    r = ds.render_uv(bounces=5)
+    assert same_bits(r["depth"], g["depth"]) and same_bits(r["normal"], g["normal"])
+    assert np.abs(r["color"].astype(np.float64) - g["color"].astype(np.float64)).max() <= 1e-4
+    assert same_bits(r["color"], plain["color"]) and r["ray_count"] == int(g["ray_count"]) == plain["ray_count"]
+    assert _uv_close(r["uv"], g["uv"])
+    assert int((r["depth"].view(np.uint32) != plain["depth"].view(np.uint32)).sum()) > 300
+    r2 = ds.render(bounces=5)           # the three-buffer call honours the bit too
+    assert same_bits(r2["depth"], r["depth"]) and same_bits(r2["normal"], r["normal"]) and same_bits(r2["color"], r["color"])
+    with pytest.raises(RuntimeError):   # not for the device-buffer calls
+        ds.render_device(1, 1, 1)
+    ds.close()
+    for seed in range(6):
+        sc = ca.HostScene.parse(_random_scene(seed + 40, w=80, h=48))
+        assert sc.ok
+        o = oracle.oracle_render(sc, bounces=3, threads=os.cpu_count() or 4, uv=True, ignore_transparent_primary=True)
+        x = ca.DeviceScene(sc)
+        x.set_variant(ca.VAR_IGNORE_TRANSPARENT | ca.VAR_EXACT_POW)
+        got = x.render_uv(bounces=3)
+        assert_parity(got, o, what=f"ignore_transparent seed {seed}")
+        assert got["ray_count"] == o["ray_count"]
+        x.close()

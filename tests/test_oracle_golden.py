@@ -233,3 +233,24 @@ def test_oracle_texture_coordinates_match_reference_fixture(ca, name, w, h):
     if ref is not None and hasattr(ref, "ref_render_uv"):
         live = oracle.ref_render(s, bounces=0, threads=4, uv=True)
         assert np.array_equal(live["uv"].view(np.uint32), g["uv"].view(np.uint32))
+
+
+def test_oracle_ignore_transparent_matches_reference_fixture(ca):
+    """ray_cast's ninth argument (inc/ray_cast.hpp:30,39-40: objects with a transparent material are skipped) — the one
+    branch of SURVEY §8(a) without a restatement until round 4, because no caller of the reference passes true.  The oracle's
+    kernel.hpp:52 cast with the flag set, against a fixture the reference build produced the same way (its harness calls the
+    reference's ray_cast with `true`; tests/golden/make_golden.py), and live against that build where it exists.
+    sphere_plane.json holds a transparent sphere: the primary hit changes in hundreds of pixels, the colour in none
+    (ray_color makes its own casts, with false: shading.hpp:32,123)."""
+    g = np.load(os.path.join(GOLD, "ignore_transparent_sphere_plane_96x54_b5.npz"))
+    s = load_scene(ca, "sphere_plane", 96, 54)
+    r = oracle.oracle_render(s, bounces=5, threads=4, uv=True, ignore_transparent_primary=True)
+    plain = oracle.oracle_render(s, bounces=5, threads=4)
+    for k in ("depth", "normal", "color", "uv"):
+        assert same_bits(r[k], g[k]), k
+    assert np.array_equal(r["hit_id"], g["hit_id"]) and r["ray_count"] == int(g["ray_count"]) == plain["ray_count"]
+    assert int((r["hit_id"] != plain["hit_id"]).sum()) > 300 and same_bits(r["color"], plain["color"])
+    if oracle.ref_lib() is not None:
+        live = oracle.ref_render(s, bounces=5, threads=4, uv=True, ignore_transparent_primary=True)
+        for k in ("depth", "normal", "color", "uv"):
+            assert same_bits(r[k], live[k]), k
