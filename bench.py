@@ -606,17 +606,19 @@ def main():
         c4_hs = ca.HostScene.load(scenes.make_bunny_grid(tempfile.mkdtemp(prefix=f"c4_r{rank}_")))
         # (12 steps after 4 of warm-up: the dispatch order is rebuilt from measured costs over the first launches of a shape, and
         #  a part of a frame — 5 waves per slot at N = 8 — feels an order that has not settled: 6 steps after 2 read 6 % slower)
-        _, c4_tiler, _, c4_dt, c4_rays, c4_kern, _ = measure(c4_hs, "strong", "rank0", 12, 4, False)
+        # (a gloo rehearsal moves every 470 MB frame through host memory: three steps there)
+        c4_steps, c4_warm = (12, 4) if (world == 1 or backend == "nccl") else (3, 1)
+        _, c4_tiler, _, c4_dt, c4_rays, c4_kern, _ = measure(c4_hs, "strong", "rank0", c4_steps, c4_warm, False)
         c4_leg = {"workload": "4x4 bunny grid (16 meshes x 1000 triangles) @4096x4096 bounces=%d, one frame per step row-tiled "
                               "over %d GPU(s), gathered to rank 0" % (args.bounces, world),
-                  "n_gpus": world, "steps": 12, "frame_ms": c4_dt / 12 * 1e3, "mrays_per_s": c4_rays * 12 / c4_dt / 1e6,
+                  "n_gpus": world, "steps": c4_steps, "frame_ms": c4_dt / c4_steps * 1e3, "mrays_per_s": c4_rays * c4_steps / c4_dt / 1e6,
                   "rays_per_frame": c4_rays, "kernel_ms_avg_over_ranks": c4_kern}
         # the same with two frames in flight (--in-flight 2): a rank's part of ONE frame is 5 waves per slot at N = 8 and ends in a
         # tail of its dearest tiles (one 8x8 tile = one wave, up to 5x the mean); the next frame's first waves fill that tail
         del c4_tiler
-        _, c4_tiler, _, c4_dt2, c4_rays2, _, _ = measure(c4_hs, "strong", "rank0", 12, 4, False, 2)
-        c4_leg["frame_ms_two_in_flight"] = c4_dt2 / 12 * 1e3
-        c4_leg["mrays_per_s_two_in_flight"] = c4_rays2 * 12 / c4_dt2 / 1e6
+        _, c4_tiler, _, c4_dt2, c4_rays2, _, _ = measure(c4_hs, "strong", "rank0", c4_steps, c4_warm, False, 2)
+        c4_leg["frame_ms_two_in_flight"] = c4_dt2 / c4_steps * 1e3
+        c4_leg["mrays_per_s_two_in_flight"] = c4_rays2 * c4_steps / c4_dt2 / 1e6
         if world == 1:
             c4_ds = ca.DeviceScene(c4_hs, device=local_rank)
             c4_ds.set_variant(ca.VAR_STATS)

@@ -803,6 +803,14 @@ def _axis_plane_scene(case, w=64, h=40):
                  {"type": "plane", "point": [0, 0, -4], "normal": [-0.0, -0.0, 0.5], "material": 1}]
         if case == "eye_on_plane":
             eye = [0.0, -2.0, -3.5]  # on the floor plane: a zero numerator for every primary ray
+    elif case == "eye_near_flt_max":
+        # the eye so high that (point - origin).y overflows to -inf for walls normal to x and z — the reference then
+        # multiplies inf by the normal's zero into a NaN and MISSES those walls; a one-product numerator would report hits
+        eye = [0.0, 3.39e38, -3.5]
+        objs += [{"type": "plane", "point": [-3, -1e37, 0], "normal": [1, -0.0, 0], "material": 1},
+                 {"type": "plane", "point": [3, -1e37, 0], "normal": [-1, 0, -0.0], "material": 2},
+                 {"type": "plane", "point": [0, -1e37, 4], "normal": [0, 0, -1], "material": 2},
+                 {"type": "plane", "point": [0, 3.0e38, 0], "normal": [0, 1, 0], "material": 1}]
     elif case == "one_axis_only":
         objs += [{"type": "plane", "point": [0, -1.5, 0], "normal": [0, 1, 0], "material": 1},
                  {"type": "plane", "point": [1, 0, 5], "normal": [0.2, 0.1, -1], "material": 2}]
@@ -818,12 +826,13 @@ def _axis_plane_scene(case, w=64, h=40):
         objs += [{"type": "plane", "point": [0, -1.5, 0], "normal": [0, 1e-38, 0], "material": 1},
                  {"type": "plane", "point": [0, 0, 5], "normal": [0, 0, -1e-30], "material": 2},
                  {"type": "plane", "point": [-3, 1e-9, 0], "normal": [3e-39, 0, 0], "material": 0}]
-    cam = {"eye": eye, "up": [0, 1, 0], "look": [eye[0], eye[1], 0.0], "near_plane": 0.1, "far_plane": 100.0, "width": w, "height": h,
+    cam = {"eye": eye, "up": [0, 1, 0], "look": [0.1, -0.2, 1.0] if case == "eye_near_flt_max" else [eye[0], eye[1], 0.0], "near_plane": 0.1, "far_plane": 100.0, "width": w, "height": h,
            "ambient": 0.15}
     return json.dumps({"camera": cam, "lights": lights, "materials": mats, "objects": objs})
 
 
-@pytest.mark.parametrize("case", ["box", "eye_on_plane", "one_axis_only", "many_per_axis", "underflow", "fudge_zero", "fudge_negative"])
+@pytest.mark.parametrize("case", ["box", "eye_on_plane", "one_axis_only", "many_per_axis", "underflow", "fudge_zero", "fudge_negative",
+                                  "eye_near_flt_max"])
 def test_axis_aligned_planes(gpu, case):
     """Planes with exactly one non-zero normal component take a three-instruction path for numerator and denominator
     (the products with zero left out); with fudge <= 0 the kernel must fall back to the reference's full expression
