@@ -15,8 +15,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
             equal to the oracle's count (64 278 888 for the default workload; tested).
   roofline= the bound that binds this kernel is VALU ISSUE (the scene, <1 MB, lives in scalar cache / L2;
             HBM carries 0.007 of its peak):  achieved = wave-level VALU instructions per launch (PMC
-            SQ_INSTS_VALU of the same command, profiles/r03/counters_<workload>.json) x the mean issue cost of
-            the instructions the kernel EXECUTES (profiles/r03/valu_mix_dynamic_<workload>.json: every
+            SQ_INSTS_VALU of the same command, profiles/r04/counters_<workload>.json) x the mean issue cost of
+            the instructions the kernel EXECUTES (profiles/r04/valu_mix_dynamic_<workload>.json: every
             straight-line segment of the source counted at run time by a -DCTR_PROFILE build, its instructions
             classified in the ISA of a -DCTR_MARKS build, scripts/dynamic_mix.py; cross-checked against
             SQ_INSTS_VALU / SALU / SMEM of the shipped build) priced with the per-kind costs MEASURED on the box
@@ -108,6 +108,15 @@ def cpu_baseline(ca, host_scene, bounces, div):
     t1 = time.perf_counter()
     r1 = fn(host_scene, bounces=bounces, rows=rows1, threads=1, hit_ids=False)
     dt1 = time.perf_counter() - t1
+    # ... and, where the host shows more than 64 hardware threads (2 x 64 cores x SMT on the box: 256), the figure at 64 threads as
+    # well, on a quarter of the sample: on a host shared with seven other jobs more threads than cores did not mean more rays
+    at64 = None
+    if threads > 64:
+        t2 = time.perf_counter()
+        r2 = fn(host_scene, bounces=bounces, rows=(0, h, 8, 0, 4 * div), threads=64, hit_ids=False)
+        dt2 = time.perf_counter() - t2
+        at64 = {"value": r2["ray_count"] / dt2 / 1e6, "unit": "Mrays/s", "cores": 64,
+                "sample": f"every {4 * div}th 8-row block ({r2['depth'].shape[0]} rows, {r2['ray_count']} rays) in {dt2:.2f} s"}
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -123,7 +132,7 @@ def cpu_baseline(ca, host_scene, bounces, div):
         "sample": f"every {div}th 8-row block of the {w}x{h} frame ({r['depth'].shape[0]} rows, "
                   f"{r['ray_count']} rays) in {dt:.2f} s",
         "seconds": dt,
-        "cpu_model": model,
+        "cpu_model": model, "hardware_threads_visible": os.cpu_count(), "at_64_threads": at64,
         "one_thread": {"value": r1["ray_count"] / dt1 / 1e6 if dt1 > 0 else 0.0, "unit": "Mrays/s",
                        "sample": f"every {div * threads}th 8-row block ({r1['depth'].shape[0]} rows, "
                                  f"{r1['ray_count']} rays) in {dt1:.2f} s"},
@@ -318,7 +327,8 @@ def extras(ca, hs, args, ds):
 
 PROFILE_WORKLOADS = {"bunny": "bunny.json@1920x1080b5", "dense64k": "bunny_dense3.json@1920x1080b5",
                      "c4": "bunny_grid4x4.json@4096x4096b5"}
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_ROUND = "r04"
+PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
 
 
 def kernel_source_hash():
@@ -352,7 +362,7 @@ def roofline_from_profiles(workload, kern_avg_ms, counters_json):
         return roof
     have, want = cnt.get("kernel_source_sha256"), kernel_source_hash()
     if have != want:
-        roof["stale"] = f"profiles/r03 describes kernel source {have}, this tree is {want}: no fraction is claimed"
+        roof["stale"] = f"profiles/{PROFILE_ROUND} describes kernel source {have}, this tree is {want}: no fraction is claimed"
         return roof
     cost = mix["mean_issue_cycles_per_valu"]
     cycles = cnt["cycles_per_launch"]
@@ -360,7 +370,7 @@ def roofline_from_profiles(workload, kern_avg_ms, counters_json):
     # The kernel's CYCLE count per launch is what the counters pin (same code, same work); the clock the chip holds
     # differs between a profiled and an un-profiled run (MI355X_MICROARCH.md, DVFS).  So
     #   frac = VALU issue cycles the launch needs / SIMD cycles it had = valu_insts x mean issue cost / (1024 x cycles_per_launch)
-    # is recomputable from profiles/r03 alone; this run's kernel time only scales achieved and peak by the same clock.
+    # is recomputable from profiles/<round> alone; this run's kernel time only scales achieved and peak by the same clock.
     frac = cnt["valu_insts_per_launch"] * cost / (1024.0 * cycles)
     roof.update({
         "frac": frac, "traffic": traffic, "cycles_per_launch": cycles, "kernel_ms_in_pmc_pass": cnt["kernel_ns_in_pmc_pass"] * 1e-6,
@@ -371,8 +381,8 @@ def roofline_from_profiles(workload, kern_avg_ms, counters_json):
         "issue_cost_cycles": {"F_vgpr_only": 2.2, "H_sgpr_operand_cmp_packed_min3": 4.1, "Q_transcendental": 8.1},
         "simds": 1024, "hbm_bytes_per_launch": traffic, "hbm_peak_gbs": HBM_PEAK_GBS,
         "wait_any_share_of_wave_cycles": (cnt["wait_any_quadcycles"] / cnt["wave_quadcycles_per_launch"]) if cnt.get("wave_quadcycles_per_launch") else None,
-        "source": f"profiles/r03/counters_{tag}.json (rocprofv3 --pmc passes of bench.py on this workload), "
-                  f"profiles/r03/valu_mix_dynamic_{tag}.json (execution-weighted mix, scripts/dynamic_mix.py), profiles/r02/valu_issue.txt"})
+        "source": f"profiles/{PROFILE_ROUND}/counters_{tag}.json (rocprofv3 --pmc passes of bench.py on this workload), "
+                  f"profiles/{PROFILE_ROUND}/valu_mix_dynamic_{tag}.json (execution-weighted mix, scripts/dynamic_mix.py), profiles/r02/valu_issue.txt"})
     ij = os.path.join(PROFILE_DIR, "issue_mix_measured.json")
     if os.path.exists(ij):
         # the additive pricing (sum of per-kind costs) against a MEASURED stream of the kernel's mix: mixing plain and
@@ -597,6 +607,62 @@ def main():
         if rank == 0:
             print(f"check: {frames} gathered frame(s) bitwise equal to the single-process render", file=sys.stderr, flush=True)
 
+    # ---- the line's core: everything the timed region produced ----
+    out = None
+    if rank == 0:
+        total_rays = rays_step * args.steps
+        value = total_rays / dt_max / 1e6
+        workload = f"{os.path.basename(args.scene)}@{w}x{h}b{args.bounces}"
+        # roofline of the dominant (only) kernel, per launch: VALU issue (the committed counters describe ONE launch of ONE whole
+        # frame: no fraction is claimed for a step of several frames or a part of a frame)
+        roof = roofline_from_profiles(workload if (world == 1 and frames == 1 and not sim) else "", kern_avg, args.counters_json)
+        config = {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
+                              f"{frames} frame(s)/step row-tiled over {world} GPU(s), "
+                              + ("frame f gathered to rank f mod N" if tiler.rotate_roots else "gather to rank 0"),
+                  "tile_order": "expensive tiles first, costs recorded by the previous launch of the same "
+                                "shape (first launch of a shape: blocks of tiles from the image centre outwards)",
+                  "kernel_ms_image_order": kern_io,
+                  "dist": dist_info,
+                  "frames_per_step": frames, "rays_per_step": rays_step,
+                  "frame_ms": dt_max / args.steps * 1e3 / frames,
+                  "unique_mrays_per_s": (rays_step - frames * w * h) * args.steps / dt_max / 1e6,
+                  "steps_in_flight": args.in_flight}
+        for tag, key in (("dense64k", "dense_64k_roofline"), ("c4", "c4_roofline")):
+            r_ = roofline_from_profiles(PROFILE_WORKLOADS[tag], 0.0, "")
+            if r_.get("frac") is not None:  # (constants of the committed PMC passes: that scene is not timed live here)
+                config[key] = {k: r_[k] for k in ("frac", "valu_insts_per_launch", "mean_issue_cycles_per_valu", "cycles_per_launch",
+                                                  "kernel_ms_in_pmc_pass", "hbm_bytes_per_launch", "source")}
+        out = {
+            "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": config,
+            "roofline": roof,
+        }
+
+    # ---- untimed side measurements.  They involve collectives that have never run on more than one GPU: should one of them
+    #      hang, a watchdog prints the line as it stands (config.extras says so) and ends every rank, so that the timed result —
+    #      what the run was for — is never lost to an extra ----
+    import threading
+    printed = threading.Lock()
+
+    def emit_and_leave(reason):
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            out["config"]["extras"] = reason
+            print(json.dumps(out), flush=True)
+        else:
+            time.sleep(3.0)   # (rank 0 prints first)
+        os._exit(0)
+
+    deadline = float(os.environ.get("CUTRACE_BENCH_EXTRAS_DEADLINE_S", "900" if world == 1 else "420"))
+    watchdog = threading.Timer(deadline, emit_and_leave, args=(f"abandoned after {deadline:.0f} s (a side measurement did not return)",))
+    watchdog.daemon = True
+    if not args.no_extras:
+        watchdog.start()
+
     # BASELINE config 5 next to the metric's workload, at every N the driver runs: the 4x4 bunny grid @4096x4096, ONE frame
     # per step row-tiled over all ranks and gathered to rank 0 (strong scaling), untimed for `value`
     c4_leg = None
@@ -613,6 +679,8 @@ def main():
                               "over %d GPU(s), gathered to rank 0" % (args.bounces, world),
                   "n_gpus": world, "steps": c4_steps, "frame_ms": c4_dt / c4_steps * 1e3, "mrays_per_s": c4_rays * c4_steps / c4_dt / 1e6,
                   "rays_per_frame": c4_rays, "kernel_ms_avg_over_ranks": c4_kern}
+        if rank == 0:
+            out["config"]["c4_strong"] = c4_leg
         # the same with two frames in flight (--in-flight 2): a rank's part of ONE frame is 5 waves per slot at N = 8 and ends in a
         # tail of its dearest tiles (one 8x8 tile = one wave, up to 5x the mean); the next frame's first waves fill that tail
         del c4_tiler
@@ -627,55 +695,26 @@ def main():
             c4_leg["live_lanes"] = _live_summary(ca.DeviceScene.lane_stats(reset=True))
             c4_ds.close()
         del c4_tiler
-    two = None
     if not args.no_extras and args.in_flight == 1 and not sim:
         # the timed workload once more with two steps in flight (--in-flight 2), untimed for `value`
         _, t2_tiler, _, t2_dt, t2_rays, _, _ = measure(hs, args.scaling, args.roots, args.steps, args.warmup, False, 2)
-        two = {"ms_per_step": t2_dt / args.steps * 1e3, "mrays_per_s": t2_rays * args.steps / t2_dt / 1e6,
-               "what": "consecutive steps alternate between two scene handles on two streams: the first waves of step k+1 fill the "
-                       "slots the tail of step k leaves empty; `value` above is measured with one launch after the other"}
+        if rank == 0:
+            out["config"]["two_steps_in_flight"] = {
+                "ms_per_step": t2_dt / args.steps * 1e3, "mrays_per_s": t2_rays * args.steps / t2_dt / 1e6,
+                "what": "consecutive steps alternate between two scene handles on two streams: the first waves of step k+1 fill the "
+                        "slots the tail of step k leaves empty; `value` above is measured with one launch after the other"}
         del t2_tiler
     if rank == 0:
-        total_rays = rays_step * args.steps
-        value = total_rays / dt_max / 1e6
-        workload = f"{os.path.basename(args.scene)}@{w}x{h}b{args.bounces}"
-        # ---- roofline of the dominant (only) kernel, per launch: VALU issue ----
-        # (the committed counters describe ONE launch of ONE whole frame: no fraction is claimed for a step of several frames
-        #  or a part of a frame)
-        roof = roofline_from_profiles(workload if (world == 1 and frames == 1 and not sim) else "", kern_avg, args.counters_json)
-        config = {"workload": f"{os.path.basename(args.scene)}@{w}x{h} bounces={args.bounces} fudge=1e-3, "
-                              f"{frames} frame(s)/step row-tiled over {world} GPU(s), "
-                              + ("frame f gathered to rank f mod N" if tiler.rotate_roots else "gather to rank 0"),
-                  "tile_order": "expensive tiles first, costs recorded by the previous launch of the same "
-                                "shape (first launch of a shape: blocks of tiles from the image centre outwards)",
-                  "kernel_ms_image_order": kern_io,
-                  "dist": dist_info,
-                  "frames_per_step": frames, "rays_per_step": rays_step,
-                  "frame_ms": dt_max / args.steps * 1e3 / frames,
-                  "unique_mrays_per_s": (rays_step - frames * w * h) * args.steps / dt_max / 1e6}
         if world == 1 and not args.no_extras:
-            config.update(extras(ca, hs, args, ds))
-        if c4_leg:
-            config["c4_strong"] = c4_leg
-        if two:
-            config["two_steps_in_flight"] = two
-        config["steps_in_flight"] = args.in_flight
-        for tag, key in (("dense64k", "dense_64k_roofline"), ("c4", "c4_roofline")):
-            r_ = roofline_from_profiles(PROFILE_WORKLOADS[tag], 0.0, "")
-            if r_.get("frac") is not None:  # (constants of the committed PMC passes: that scene is not timed live here)
-                config[key] = {k: r_[k] for k in ("frac", "valu_insts_per_launch", "mean_issue_cycles_per_valu", "cycles_per_launch",
-                                                  "kernel_ms_in_pmc_pass", "hbm_bytes_per_launch", "source")}
-        out = {
-            "metric": "Mrays/sec (primary+secondary)", "value": value, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": config,
-            "roofline": roof,
-        }
+            out["config"].update(extras(ca, hs, args, ds))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ca, hs, args.bounces, args.cpu_sample_div)
-        print(json.dumps(out), flush=True)
+    watchdog.cancel()
+    if printed.acquire(blocking=False):
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    else:
+        time.sleep(10.0)   # (the watchdog is printing and will end the process)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

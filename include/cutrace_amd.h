@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 2   /* 2 (round 3): CTR_E_DELIVERY, ctr_multi_submit / ctr_multi_wait, ctr_render_uv, ctr_set_variant rejects unknown bits
+#define CTR_ABI_VERSION 3   /* 3 (round 4): CTR_VAR_IGNORE_TRANSPARENT, CTR_VAR_MERGE, ctr_debug_lane_stats
+                             * 2 (round 3): CTR_E_DELIVERY, ctr_multi_submit / ctr_multi_wait, ctr_render_uv, ctr_set_variant rejects unknown bits
                              * (1 silently ignored the bits CTR_VAR_TRI_LDS = 1, CTR_VAR_VMEM = 64, CTR_VAR_SMEM = 128 that round 2 removed) */
 
 /* ---- status codes ------------------------------------------------------- */

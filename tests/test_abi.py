@@ -20,7 +20,7 @@ def test_hip_library_exports_every_declared_symbol():
     L = _lib.hip_lib()
     for n in names:
         assert hasattr(L, n), f"libcutrace_amd.so does not export {n}"
-    assert L.ctr_abi_version() == 2
+    assert L.ctr_abi_version() == 3
 
 
 def test_host_library_exports_every_declared_symbol():
