@@ -559,15 +559,16 @@ int refresh_linear_meshes(ctr_scene *s) {
             for (int a = 0; a < 3; a++) { g4.lo[a][c] = 3.4028235e38f; g4.hi[a][c] = 3.4028235e38f; }
             g4.child[c] = BVH_LEAF_FLAG;
           }
+          // (slot 0: the next spare node or the root; slots 1..3: guard leaves — unused slots last, the walk skips an empty second pair)
+          for (int a = 0; a < 3; a++) { g4.lo[a][0] = -3.0e38f; g4.hi[a][0] = 3.0e38f; }
+          g4.child[0] = (j + 1 < n_spare) ? (M.node_count + j + 1) : 0u;
           for (int c = 0; c < 3; c++) {
             const size_t gi = (size_t)3 * j + c;
             if (gi >= groups.size()) break;
             const DObj &Rm = s->h_meshes[s->n_mesh + 1u + groups[gi].rank];
-            for (int a = 0; a < 3; a++) { g4.lo[a][c] = Rm.f[a]; g4.hi[a][c] = Rm.f[3 + a]; }
-            g4.child[c] = BVH_LEAF_FLAG | (groups[gi].count << 24) | (M.tri_count + groups[gi].first);
+            for (int a = 0; a < 3; a++) { g4.lo[a][1 + c] = Rm.f[a]; g4.hi[a][1 + c] = Rm.f[3 + a]; }
+            g4.child[1 + c] = BVH_LEAF_FLAG | (groups[gi].count << 24) | (M.tri_count + groups[gi].first);
           }
-          for (int a = 0; a < 3; a++) { g4.lo[a][3] = -3.0e38f; g4.hi[a][3] = 3.0e38f; }
-          g4.child[3] = (j + 1 < n_spare) ? (M.node_count + j + 1) : 0u;  // the next spare node, or the root
         }
         HIP_TRY(hipMemcpy(s->d_nodes4 + M.node_begin + M.node_count, chain.data(), chain.size() * sizeof(DNode4), hipMemcpyHostToDevice));
       }
