@@ -392,6 +392,7 @@ int attach_order(ctr_scene *s, RenderLaunch &L, bool count) {
 #define CTR_GUARD_SLOTS 64u
 #define CTR_MERGED_SPARE_NODES ((CTR_GUARD_SLOTS + 2u) / 3u)  // the merged tree: three meshes' guard leaves per spare node
 #define CTR_MIRROR_MESH_TRIS 16u
+#define CTR_SECOND_ORDER_MAX_EYES 8u
 #define CTR_VIRTUAL_EYES_MAX 4096u  // (round 3: 96 — a 90-camera path through a room of five reflecting walls got images for its first 16 cameras only)
 int refresh_linear_meshes(ctr_scene *s) {
   constexpr double TOL = 1.0 / 131072.0;
@@ -439,7 +440,12 @@ int refresh_linear_meshes(ctr_scene *s) {
                                    "(DESIGN.md section 2) covers the first %zu only\n", n_eyes, mirrors.size(), CTR_VIRTUAL_EYES_MAX, first.size());
       warned = true;
     }
-    if (first.size() * (mirrors.size() ? mirrors.size() - 1 : 0) + origins.size() <= CTR_VIRTUAL_EYES_MAX)
+    // Images of images (two reflections in a row): for up to CTR_SECOND_ORDER_MAX_EYES cameras.  The guard records serve every
+    // launch on the handle, whichever of its cameras the launch renders, so each camera's images cost every frame: with all
+    // second-order images of a 90-camera path (2 340 points) the bunny room's frames ran 14 % slower for a handful of guard
+    // triangles (bench.py config.campath_ms 1.17 -> 1.34 ms); first-order images of every camera stay.
+    if (n_eyes <= CTR_SECOND_ORDER_MAX_EYES &&
+        first.size() * (mirrors.size() ? mirrors.size() - 1 : 0) + origins.size() <= CTR_VIRTUAL_EYES_MAX)
       for (const auto &f : first)
         for (size_t m = 0; m < mirrors.size(); m++)
           if (m != f.second) origins.push_back(image(f.first, mirrors[m]));
