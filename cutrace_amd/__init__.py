@@ -27,6 +27,7 @@ VAR_NO_DIRECT = 1024
 VAR_IMAGE_ORDER_FIRST = 2048
 VAR_MERGE = 4096
 VAR_IGNORE_TRANSPARENT = 8192
+VAR_NO_OCCLUDER_MAP = 16384
 
 
 @contextlib.contextmanager
@@ -253,7 +254,7 @@ class DeviceScene:
     @staticmethod
     def lane_stats(reset=True):
         """Live-lane statistics of the VAR_STATS launches since the last reset (ctr_debug_lane_stats), decoded."""
-        raw = np.zeros(80, np.uint64)
+        raw = np.zeros(96, np.uint64)
         if _lib.hip_lib().ctr_debug_lane_stats(raw.ctypes.data, 1 if reset else 0):
             raise RuntimeError("ctr_debug_lane_stats failed")
         c = [int(x) for x in raw]
@@ -262,7 +263,10 @@ class DeviceScene:
                "live_fraction": live / (64.0 * trips) if trips else None,
                "live_fraction_of_in_image_lanes": (live / trips) / (c[75] / c[74]) if trips and c[74] and c[75] else None,
                "trips_by_live_lanes_1_8_to_57_64": c[64:72], "trips_mixing_kinds": c[76], "waves": c[74],
-               "merged_walks": c[78], "merged_walks_redone": c[77]}
+               "merged_walks": c[78], "merged_walks_redone": c[77],
+               "shadow_casts_at_meshes": {"wave_casts": c[80], "receivers_all_off_mesh": c[81], "of_those_unoccluded_by_meshes": c[82],
+                                          "unoccluded_by_meshes_any_receiver": c[83], "skipped_whole_by_occluder_map": c[84],
+                                          "lanes_skipped_by_occluder_map": c[85], "shadow_lanes": c[86]}}
         kinds = {}
         for d in range(16):
             for name, base in (("radiance", 0), ("shadow", 16)):

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 3   /* 3 (round 4): CTR_VAR_IGNORE_TRANSPARENT, CTR_VAR_MERGE, ctr_debug_lane_stats
+#define CTR_ABI_VERSION 3   /* 3 (round 4): CTR_VAR_IGNORE_TRANSPARENT, CTR_VAR_MERGE, CTR_VAR_NO_OCCLUDER_MAP, ctr_debug_lane_stats
                              * 2 (round 3): CTR_E_DELIVERY, ctr_multi_submit / ctr_multi_wait, ctr_render_uv, ctr_set_variant rejects unknown bits
                              * (1 silently ignored the bits CTR_VAR_TRI_LDS = 1, CTR_VAR_VMEM = 64, CTR_VAR_SMEM = 128 that round 2 removed) */
 
@@ -271,6 +271,7 @@ int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
                                    * ray_cast's ignore_transparent = true (inc/ray_cast.hpp:30,39-40): objects whose material is transparent
                                    * (transparency >= 1e-6, default_schema.hpp:334) do not exist for it.  Colour is unchanged: ray_color's own casts
                                    * pass false (shading.hpp:32,123).  No caller of the reference passes true; this is the branch, restated. */
+#define CTR_VAR_NO_OCCLUDER_MAP 16384u /* never consult the per-light occluder-distance maps (shadow rays that certainly meet no mesh triangle skip the meshes) */
 #define CTR_VAR_NO_OCC6 512u      /* never pick the build compiled for 6 waves per SIMD (chosen for scenes with >= 1000 mesh triangles) */
 /* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
  * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles
@@ -296,13 +297,14 @@ int ctr_selftest_exact_math(uint64_t *n_mismatch);
 int ctr_last_counters(ctr_scene *scene, uint64_t *out16);
 /* Diagnostic: how many of a wave's 64 lanes are alive, trip by trip, in the CTR_VAR_STATS launches since the last reset
  * (one lane = one pixel for the pixel's whole life; the reference's recursion, inc/shading.hpp:126-150, is what makes
- * lanes finish at different times).  80 words: [0..15] lanes casting a radiance ray at recursion depth d (0 = primary),
+ * lanes finish at different times).  96 words: [0..15] lanes casting a radiance ray at recursion depth d (0 = primary),
  * summed over the trips; [16..31] lanes casting a shadow ray for a hit at depth d; [32..47] / [48..63] trips in which at
  * least one lane casts such a ray; [64..71] trips by number of live lanes (1-8, 9-16, ... 57-64); [72] trips; [73] live
  * lanes summed over the trips; [74] waves; [75] lanes inside the image summed over the waves; [76] trips whose live lanes
  * cast for more than one (kind, depth); [77] wave casts the merged walk (one tree over all meshes' triangles) handed back
- * to the two-level walk, [78] wave casts that went through the merged walk.  Process-wide (one table per device code object), not per scene handle. */
-int ctr_debug_lane_stats(uint64_t *out80, int reset);
+ * to the two-level walk, [78] wave casts that went through the merged walk; [80] shadow wave casts that reach the mesh phase, [81] those whose
+ * live lanes all start on a plane or sphere, [82] those of [81] with no occluder found among the meshes, [83] those of [80] with none.  Process-wide (one table per device code object), not per scene handle. */
+int ctr_debug_lane_stats(uint64_t *out96, int reset);
 /* ctr_render plus a FOURTH output: the texture coordinates ray_cast hands back for the primary hit (its tex_coords,
  * inc/ray_cast.hpp:47 — triangle::uv_for, plane::uv_for, the sphere's atan2 / asin pair, a mesh's (hit.x, hit.y);
  * inc/default_schema.hpp:37-46,138-139,169-178,246-249), uv2 = 2 floats per pixel, row-major like depth, (0, 0) on a
