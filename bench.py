@@ -337,7 +337,7 @@ def kernel_source_hash():
     import hashlib
     from cutrace_amd import build
     hh = hashlib.sha256()
-    for f in ("cutrace_amd/csrc/render_kernel.hip", "cutrace_amd/csrc/scene_device.h", "cutrace_amd/csrc/bvh.h", "cutrace_amd/csrc/occl.h",
+    for f in ("cutrace_amd/csrc/render_kernel.hip", "cutrace_amd/csrc/scene_device.h", "cutrace_amd/csrc/bvh.h",
               "include/cutrace_amd.h"):
         hh.update(open(os.path.join(ROOT, f), "rb").read())
     hh.update(" ".join(x for x in build.HIP_FLAGS if not x.startswith("-I")).encode())

@@ -27,7 +27,6 @@ VAR_NO_DIRECT = 1024
 VAR_IMAGE_ORDER_FIRST = 2048
 VAR_MERGE = 4096
 VAR_IGNORE_TRANSPARENT = 8192
-VAR_NO_OCCLUDER_MAP = 16384
 
 
 @contextlib.contextmanager
@@ -265,8 +264,7 @@ class DeviceScene:
                "trips_by_live_lanes_1_8_to_57_64": c[64:72], "trips_mixing_kinds": c[76], "waves": c[74],
                "merged_walks": c[78], "merged_walks_redone": c[77],
                "shadow_casts_at_meshes": {"wave_casts": c[80], "receivers_all_off_mesh": c[81], "of_those_unoccluded_by_meshes": c[82],
-                                          "unoccluded_by_meshes_any_receiver": c[83], "skipped_whole_by_occluder_map": c[84],
-                                          "lanes_skipped_by_occluder_map": c[85], "shadow_lanes": c[86]}}
+                                          "unoccluded_by_meshes_any_receiver": c[83]}}
         kinds = {}
         for d in range(16):
             for name, base in (("radiance", 0), ("shadow", 16)):

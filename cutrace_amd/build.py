@@ -24,7 +24,7 @@ CLI = os.path.join(PKG, "cutrace")
 
 HOST_SRCS = [os.path.join(HOST, "scene_host.cpp"), os.path.join(HOST, "images.cpp")]
 HIP_SRCS = [os.path.join(CSRC, "render_kernel.hip"), os.path.join(CSRC, "ctr_api.cpp"), os.path.join(CSRC, "bvh.cpp"),
-            os.path.join(CSRC, "occl.cpp"), os.path.join(CSRC, "ctr_multi.hip")]
+            os.path.join(CSRC, "ctr_multi.hip")]
 CLI_SRCS = [os.path.join(HOST, "main.cpp")]
 
 HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I" + INC]

@@ -21,7 +21,6 @@
 #include <vector>
 
 #include "bvh.h"
-#include "occl.h"
 #include "cutrace_amd.h"
 #include "scene_device.h"
 
@@ -118,8 +117,6 @@ struct ctr_scene {
   DNode *d_nodes = nullptr;
   DNode4 *d_nodes4 = nullptr;
   float *d_gnorm = nullptr;
-  float *d_occl = nullptr;            // per-light occluder-distance maps (occl.h), n_light x CTR_OCCL_CELLS floats; null: none
-  std::vector<uint8_t> light_in_plane; // per light: it lies in the plane of some mesh triangle (refresh_linear_meshes) -> its map is all zero
   DLight *d_lights = nullptr;
   DMat *d_mats = nullptr;
   uint32_t n_obj = 0, n_tri = 0, n_light = 0, n_mat = 0;
@@ -271,7 +268,6 @@ void fill_launch(const ctr_scene *s, RenderLaunch &L) {
   L.nodes = s->d_nodes;
   L.nodes4 = s->d_nodes4;
   L.gnorm = s->d_gnorm;
-  L.occl = (s->user_variant & CTR_VAR_NO_OCCLUDER_MAP) ? nullptr : s->d_occl;
   L.lights = s->d_lights;
   L.mats = s->d_mats;
   L.n_obj = s->n_obj;
@@ -458,7 +454,6 @@ int refresh_linear_meshes(ctr_scene *s) {
   std::vector<uint32_t> m_keys;  // merged tree: the keys (mesh rank << 24 | file index) of every mesh's risky triangles
   bool m_any_linear = false;
   uint32_t rank = 0;             // of the current mesh among the non-empty meshes, scene order (guards are in scene order)
-  s->light_in_plane.assign(s->h_lights.size(), 0);
   for (ctr_scene::MeshGuard &g : s->guards) {
     if (g.mesh_pos < 0) continue;
     const uint32_t g_rank = rank++;
@@ -476,10 +471,9 @@ int refresh_linear_meshes(ctr_scene *s) {
       bool hit = false;
       for (const P3 &o : origins)
         if (point_in_plane(o.x, o.y, o.z)) hit = true;
-      for (size_t li = 0; li < s->h_lights.size(); li++) {
-        const DLight &l = s->h_lights[li];
+      for (const DLight &l : s->h_lights) {
         if (l.type == CTR_LIGHT_POINT) {
-          if (point_in_plane(l.vx, l.vy, l.vz)) { hit = true; s->light_in_plane[li] = 1; }
+          if (point_in_plane(l.vx, l.vy, l.vz)) hit = true;
         } else {
           const double len = sqrt((double)l.vx * l.vx + (double)l.vy * l.vy + (double)l.vz * l.vz);
           if (len > 0.0 && fabs(l.vx * q[0] + l.vy * q[1] + l.vz * q[2]) <= TOL * len) hit = true;
@@ -1064,34 +1058,6 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
     return st;
   }
   dbg_stamp("guard records");
-  // ---- per-light occluder-distance maps (occl.h): point lights of scenes with meshes; one builder thread per light ----
-  if (s->mesh_tris && !lights.empty()) {
-    std::vector<OcclTri> otris;
-    otris.reserve(s->mesh_tris);
-    for (uint64_t i = 0; i < d->n_objects; i++) {
-      const ctr_object &o = d->objects[i];
-      if (o.type != CTR_OBJ_MESH) continue;
-      for (uint64_t k = 0; k < o.tri_count; k++) {
-        const ctr_triangle &t = d->triangles[o.tri_begin + k];
-        otris.push_back(OcclTri{{{t.p1.x, t.p1.y, t.p1.z}, {t.p2.x, t.p2.y, t.p2.z}, {t.p3.x, t.p3.y, t.p3.z}}});
-      }
-    }
-    std::vector<float> maps((size_t)lights.size() * CTR_OCCL_CELLS, 0.0f);  // (zero: nothing is ever nearer — suns, lights in a triangle's plane)
-    std::vector<std::thread> workers;
-    for (size_t li = 0; li < lights.size(); li++) {
-      if (lights[li].type != CTR_LIGHT_POINT || s->light_in_plane[li]) continue;
-      workers.emplace_back([&, li] {
-        const float L[3] = {lights[li].vx, lights[li].vy, lights[li].vz};
-        occl_build_point_light(L, otris.data(), otris.size(), &maps[li * CTR_OCCL_CELLS]);
-      });
-    }
-    for (std::thread &w : workers) w.join();
-    if ((er = upload((void **)&s->d_occl, maps.data(), maps.size() * sizeof(float))) != hipSuccess) {
-      ctr_scene_destroy(s);
-      return hip_fail(er, "occluder maps");
-    }
-    dbg_stamp("occluder maps");
-  }
   *out = s;
   return CTR_OK;
 }
@@ -1124,7 +1090,7 @@ int ctr_scene_set_cameras(ctr_scene *s, const ctr_camera *cams, uint32_t n) {
 void ctr_scene_destroy(ctr_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_nodes4, (void *)s->d_gnorm, (void *)s->d_occl, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
+  for (void *p : {(void *)s->d_objs, (void *)s->d_oloop, (void *)s->d_meshes, (void *)s->d_planes, (void *)s->d_tris, (void *)s->d_nodes, (void *)s->d_nodes4, (void *)s->d_gnorm, (void *)s->d_lights, (void *)s->d_mats, (void *)s->d_cams,
                   (void *)s->d_out, (void *)s->d_uv, (void *)s->d_groups, (void *)s->d_counters, (void *)s->d_shards, (void *)s->d_cost, (void *)s->d_order})
     if (p) (void)hipFree(p);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
@@ -1159,7 +1125,7 @@ int ctr_scene_set_size(ctr_scene *s, uint64_t w, uint64_t h) {
 int ctr_set_variant(ctr_scene *s, uint32_t bits) {
   if (!s) return fail(CTR_E_INVALID, "null scene");
   constexpr uint32_t KNOWN = CTR_VAR_NO_PREFILTER | CTR_VAR_NO_ANYHIT | CTR_VAR_NO_CLUSTER | CTR_VAR_STATS | CTR_VAR_EXACT_POW |
-                             CTR_VAR_NO_REORDER | CTR_VAR_NO_OCC6 | CTR_VAR_NO_DIRECT | CTR_VAR_IMAGE_ORDER_FIRST | CTR_VAR_MERGE | CTR_VAR_IGNORE_TRANSPARENT | CTR_VAR_NO_OCCLUDER_MAP;
+                             CTR_VAR_NO_REORDER | CTR_VAR_NO_OCC6 | CTR_VAR_NO_DIRECT | CTR_VAR_IMAGE_ORDER_FIRST | CTR_VAR_MERGE | CTR_VAR_IGNORE_TRANSPARENT;
   if (bits & ~KNOWN) return fail(CTR_E_INVALID, "ctr_set_variant: unknown variant bits " + std::to_string(bits & ~KNOWN));
   s->user_variant = bits;
   if ((bits & CTR_VAR_MERGE) && s->merged.reserved && !s->merged.built) {

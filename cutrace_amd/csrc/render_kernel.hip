@@ -67,7 +67,6 @@
 #include "cutrace_amd.h"
 #include "scene_device.h"
 #include "bvh.h"
-#include "occl.h"
 
 #define CADDR __attribute__((address_space(4)))
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
@@ -100,9 +99,8 @@ __device__ unsigned int g_prof[128];  // executions of the CTR_MARK segments, su
 //   [72] trips, [73] live lanes summed over the trips, [74] waves, [75] lanes inside the image summed over the waves,
 //   [76] trips in which the live lanes cast for more than one (kind, depth)
 //   [80] shadow wave casts that reach the mesh phase with live lanes, [81] those whose live lanes all start on a plane / sphere (not on a
-//        mesh or triangle), [82] those of [81] in which no lane met an occluder in the mesh phase — what a perfect per-light occluder-depth
-//        map could skip —, [83] those of [80] in which no lane met an occluder in the mesh phase, whatever the receivers
-//   [84] those of [80] whose live lanes the occluder map (occl.h) took out of the mesh phase ALL, [85] lanes it took out, [86] of how many
+//        mesh or triangle), [82] those of [81] in which no lane met an occluder in the mesh phase — what a perfect per-light occluder-distance
+//        map could skip (built, measured and removed in round 4: those are the cheap casts, profiles/r04/exp_occluder_map.txt) —, [83] those of [80] in which no lane met an occluder in the mesh phase, whatever the receivers
 //   [77] casts the merged walk handed back to the two-level walk (a mesh's AABB test failed for a lane the walk had decided,
 //        or a mesh's nearest valid t equalled min_t), [78] casts that went through the merged walk
 __device__ unsigned long long g_lane_stats[96];
@@ -324,7 +322,6 @@ struct KArgs {
   float *host_depth, *host_color, *host_normal;
   uint32_t *group_done;
   float *uv_out;      // KV_UV: texture coordinates of the primary hit, 2 floats per pixel
-  const float *occl;  // per-light occluder-distance maps (occl.h), CTR_OCCL_CELLS floats per light, or null
 };
 
 static_assert(offsetof(KArgs, planes) == 0 && offsetof(KArgs, has_mesh) == 28, "KArgs: the hot block is the first eight dwords");
@@ -540,7 +537,7 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     const bool active = MSP_ACTIVE(msp);
     const bool shadow_cast = MSP_IS_SHADOW(msp);
     const mask_t active_m = BALLOT(active);
-    mask_t shadow_m = BALLOT(shadow_cast);  // (taken here, straight from the compare: see alive_m below)
+    const mask_t shadow_m = BALLOT(shadow_cast);  // (taken here, straight from the compare: see alive_m below)
     n_casts += (unsigned long long)__builtin_popcountll(active_m);
     if (STATS) {
       st[0]++; st[5] += __builtin_popcountll(active_m);
@@ -792,46 +789,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
     TACC(2, t_planes1, t_oloop1);
     CTR_MARK(13);
     const mask_t st_shadow_entry = (STATS && ANYHIT) ? (alive_m & shadow_m) : 0ull;
-    mask_t st_skip_m = 0ull;  // STATS: lanes the occluder map took out of the mesh phase
     const mask_t st_recv_mesh = STATS ? BALLOT(recv_mesh) : 0ull;
-    // ---- occluder map (occl.h): the shadow rays among `lanes` that meet no mesh triangle before their light, for certain ----
-    // A point light's rays converge in the light, so a cube map around it can hold, per cell of directions, a lower bound of the
-    // distance from the light to ANY mesh triangle seen there (built on the host, conservative: occl.cpp).  A receiver nearer to the
-    // light than that bound has nothing between itself and the light: the lane takes no part in the mesh phase of this cast.
-    // The direction from the light to the receiver is -rd, the distance light_dist (both as the reference computes them,
-    // shading.hpp:79-84); the compare carries 2^-12 on top of the map's own 2^-10.  A sun (light_dist = inf), a light in a
-    // triangle's plane (zero map) or a non-finite ray never passes it.  54 % of C4's shadow wave casts and 73 % of the bunny
-    // room's have only such lanes (profiles/r04/exp_occluder_map.txt).
-    auto occl_skip = [&](mask_t lanes) -> mask_t {
-      const float *const maps = AK->occl;
-      if (maps == nullptr) return 0ull;
-      const float vx = -rd.x, vy = -rd.y, vz = -rd.z;
-      const float ax = fabsf(vx), ay = fabsf(vy), az = fabsf(vz);
-      const bool fx = ax >= ay && ax >= az, fy = !fx && ay >= az;
-      const float m = fx ? ax : (fy ? ay : az);
-      const float u = fx ? vy : vx, w = (fx || fy) ? vz : vy;
-      const uint32_t face = fx ? (vx < 0.0f ? 1u : 0u) : (fy ? (vy < 0.0f ? 3u : 2u) : (vz < 0.0f ? 5u : 4u));
-      const float inv = __builtin_amdgcn_rcpf(m) * (0.5f * (float)CTR_OCCL_RES);
-      // (v_cvt_i32_f32 saturates and turns a NaN into 0: any cell is as good as another for a ray that cannot be skipped anyway)
-      int c = (int)__builtin_fmaf(u, inv, 0.5f * (float)CTR_OCCL_RES), r = (int)__builtin_fmaf(w, inv, 0.5f * (float)CTR_OCCL_RES);
-      c = c < 0 ? 0 : (c > (int)CTR_OCCL_RES - 1 ? (int)CTR_OCCL_RES - 1 : c);
-      r = r < 0 ? 0 : (r > (int)CTR_OCCL_RES - 1 ? (int)CTR_OCCL_RES - 1 : r);
-      const uint32_t idx = ((li * 6u + face) * CTR_OCCL_RES + (uint32_t)r) * CTR_OCCL_RES + (uint32_t)c;
-      const float bound = INVB(lanes & shadow_m) ? maps[idx] : 0.0f;
-      return lanes & shadow_m & FCMP(bound, light_dist * (1.0f + 0x1p-12f), FC_OGT);
-    };
-#ifndef CTR_OCCL_SITE
-#define CTR_OCCL_SITE 2   /* 0: never; 1: before the top-level walk, every scene; 2: there for several meshes, after the AABB test for one */
-#endif
-    if (CTR_OCCL_SITE != 0 && BVH && (CTR_OCCL_SITE == 1 ? k_mesh != 0u : k_mesh > 1u) && (alive_m & shadow_m) != 0ull) {
-      CTR_MARK(89);  // occluder map, before the top-level walk (several meshes)
-      const mask_t skip_m = occl_skip(alive_m);
-      // (out of `alive_m` AND `shadow_m`: where a mesh is left, "a deciding shadow ray that is no longer alive" means "occluded")
-      alive_m &= ~skip_m;
-      shadow_m &= ~skip_m;
-      if (STATS) st_skip_m = skip_m;
-    }
-    if (k_mesh != 0u && (alive_m != 0ull)) {
+    if (k_mesh != 0u) {
       uint32_t t_pend = k_tlas_root;             // next top-level item: inner node or mesh leaf
       uint32_t t_stack_v = 0, t_sp = 0;        // wave-uniform stack in the lanes of one VGPR
       // ---- mesh::bound_intersects, default_schema.hpp:99-114, for the lanes in `lanes` -> the lanes that pass ----
@@ -1020,13 +979,6 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
           TACC(3, t_tl0, t_bb);
           CTR_MARK(21);
           if (bb_m == 0ull) continue;  // no lane of this wave needs the mesh
-          if (CTR_OCCL_SITE == 2 && BVH && k_mesh == 1u && (bb_m & shadow_m) != 0ull) {
-            CTR_MARK(79);  // occluder map, after the AABB test (one mesh: most casts end at the AABB test, which costs as much)
-            const mask_t skip1_m = occl_skip(bb_m);
-            if (STATS) st_skip_m |= skip1_m;
-            bb_m &= ~skip1_m;
-            if (bb_m == 0ull) continue;
-          }
           CTR_MARK(22);  // mesh entered: walk set-up
           const uint32_t beg = o_tri_begin, cnt = o_tri_count;
           if (COUNT) n_aabb_tris += INVB(bb_m) ? (unsigned long long)cnt : 0ull;
@@ -1454,11 +1406,8 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       }
     }
     if (STATS && st_shadow_entry != 0ull && lane == 0) {
-      const bool planes_only = (st_recv_mesh & st_shadow_entry) == 0ull, none_occluded = (st_shadow_entry & ~alive_m & ~st_skip_m) == 0ull;
+      const bool planes_only = (st_recv_mesh & st_shadow_entry) == 0ull, none_occluded = (st_shadow_entry & ~alive_m) == 0ull;
       atomicAdd(&g_lane_stats[80], 1ull);
-      if (st_skip_m == st_shadow_entry) atomicAdd(&g_lane_stats[84], 1ull);
-      atomicAdd(&g_lane_stats[85], (unsigned long long)__builtin_popcountll(st_skip_m));
-      atomicAdd(&g_lane_stats[86], (unsigned long long)__builtin_popcountll(st_shadow_entry));
       if (planes_only) atomicAdd(&g_lane_stats[81], 1ull);
       if (planes_only && none_occluded) atomicAdd(&g_lane_stats[82], 1ull);
       if (none_occluded) atomicAdd(&g_lane_stats[83], 1ull);
@@ -2165,7 +2114,6 @@ int launch(const RenderLaunch &L, hipStream_t stream) {
   A.host_normal = L.host_normal;
   A.group_done = L.group_done;
   A.uv_out = L.uv;
-  A.occl = L.occl;
   if (((KV & KV_UV) != 0) != (L.uv != nullptr)) return (int)hipErrorInvalidValue;
   size_t lds_bytes = (size_t)WAVES_PER_WG * A.frames * A.nf * 64 * sizeof(float);
   if (KV & KV_OCC6) lds_bytes += (size_t)WAVES_PER_WG * 5 * 64 * sizeof(float);  // PARK

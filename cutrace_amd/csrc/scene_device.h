@@ -161,7 +161,6 @@ struct RenderLaunch {
   float *color;
   float *normal;
   float *uv;                     // KV_UV: 2 floats per pixel (same indexing as depth), else null
-  const float *occl;             // per-light occluder-distance maps (occl.h) or null
   unsigned long long *shards;    // scene-owned CTR_SHARDS x CTR_SHARD_WORDS scratch the kernel adds into
   unsigned long long *counters;  // [0] ray_count, [1] max-depth bits, [2] AABB-hit triangle count (KV_COUNT), [4..9] KV_STATS
   uint32_t variant;

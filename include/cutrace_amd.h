@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CTR_ABI_VERSION 3   /* 3 (round 4): CTR_VAR_IGNORE_TRANSPARENT, CTR_VAR_MERGE, CTR_VAR_NO_OCCLUDER_MAP, ctr_debug_lane_stats
+#define CTR_ABI_VERSION 3   /* 3 (round 4): CTR_VAR_IGNORE_TRANSPARENT, CTR_VAR_MERGE, ctr_debug_lane_stats
                              * 2 (round 3): CTR_E_DELIVERY, ctr_multi_submit / ctr_multi_wait, ctr_render_uv, ctr_set_variant rejects unknown bits
                              * (1 silently ignored the bits CTR_VAR_TRI_LDS = 1, CTR_VAR_VMEM = 64, CTR_VAR_SMEM = 128 that round 2 removed) */
 
@@ -271,7 +271,6 @@ int ctr_multi_kernel_ms(ctr_multi *group, double *ms_per_device, int capacity);
                                    * ray_cast's ignore_transparent = true (inc/ray_cast.hpp:30,39-40): objects whose material is transparent
                                    * (transparency >= 1e-6, default_schema.hpp:334) do not exist for it.  Colour is unchanged: ray_color's own casts
                                    * pass false (shading.hpp:32,123).  No caller of the reference passes true; this is the branch, restated. */
-#define CTR_VAR_NO_OCCLUDER_MAP 16384u /* never consult the per-light occluder-distance maps (shadow rays that certainly meet no mesh triangle skip the meshes) */
 #define CTR_VAR_NO_OCC6 512u      /* never pick the build compiled for 6 waves per SIMD (chosen for scenes with >= 1000 mesh triangles) */
 /* Tile scheduling: every launch records what each 8x8 tile cost, and the next launch of the same
  * shape (image size, rows, frame count) on the same scene handle dispatches the expensive tiles
