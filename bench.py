@@ -663,52 +663,57 @@ def main():
     if not args.no_extras:
         watchdog.start()
 
-    # BASELINE config 5 next to the metric's workload, at every N the driver runs: the 4x4 bunny grid @4096x4096, ONE frame
-    # per step row-tiled over all ranks and gathered to rank 0 (strong scaling), untimed for `value`
-    c4_leg = None
-    if not args.no_extras and args.workload != "c4" and not sim and os.path.basename(args.scene) == "bunny.json" and not (args.width or args.height):
-        import tempfile
-        from cutrace_amd import scenes
-        c4_hs = ca.HostScene.load(scenes.make_bunny_grid(tempfile.mkdtemp(prefix=f"c4_r{rank}_")))
-        # (12 steps after 4 of warm-up: the dispatch order is rebuilt from measured costs over the first launches of a shape, and
-        #  a part of a frame — 5 waves per slot at N = 8 — feels an order that has not settled: 6 steps after 2 read 6 % slower)
-        # (a gloo rehearsal moves every 470 MB frame through host memory: three steps there)
-        c4_steps, c4_warm = (12, 4) if (world == 1 or backend == "nccl") else (3, 1)
-        _, c4_tiler, _, c4_dt, c4_rays, c4_kern, _ = measure(c4_hs, "strong", "rank0", c4_steps, c4_warm, False)
-        c4_leg = {"workload": "4x4 bunny grid (16 meshes x 1000 triangles) @4096x4096 bounces=%d, one frame per step row-tiled "
-                              "over %d GPU(s), gathered to rank 0" % (args.bounces, world),
-                  "n_gpus": world, "steps": c4_steps, "frame_ms": c4_dt / c4_steps * 1e3, "mrays_per_s": c4_rays * c4_steps / c4_dt / 1e6,
-                  "rays_per_frame": c4_rays, "kernel_ms_avg_over_ranks": c4_kern}
+    try:
+        # BASELINE config 5 next to the metric's workload, at every N the driver runs: the 4x4 bunny grid @4096x4096, ONE frame
+        # per step row-tiled over all ranks and gathered to rank 0 (strong scaling), untimed for `value`
+        c4_leg = None
+        if not args.no_extras and args.workload != "c4" and not sim and os.path.basename(args.scene) == "bunny.json" and not (args.width or args.height):
+            import tempfile
+            from cutrace_amd import scenes
+            c4_hs = ca.HostScene.load(scenes.make_bunny_grid(tempfile.mkdtemp(prefix=f"c4_r{rank}_")))
+            # (12 steps after 4 of warm-up: the dispatch order is rebuilt from measured costs over the first launches of a shape, and
+            #  a part of a frame — 5 waves per slot at N = 8 — feels an order that has not settled: 6 steps after 2 read 6 % slower)
+            # (a gloo rehearsal moves every 470 MB frame through host memory: three steps there)
+            c4_steps, c4_warm = (12, 4) if (world == 1 or backend == "nccl") else (3, 1)
+            _, c4_tiler, _, c4_dt, c4_rays, c4_kern, _ = measure(c4_hs, "strong", "rank0", c4_steps, c4_warm, False)
+            c4_leg = {"workload": "4x4 bunny grid (16 meshes x 1000 triangles) @4096x4096 bounces=%d, one frame per step row-tiled "
+                                  "over %d GPU(s), gathered to rank 0" % (args.bounces, world),
+                      "n_gpus": world, "steps": c4_steps, "frame_ms": c4_dt / c4_steps * 1e3, "mrays_per_s": c4_rays * c4_steps / c4_dt / 1e6,
+                      "rays_per_frame": c4_rays, "kernel_ms_avg_over_ranks": c4_kern}
+            if rank == 0:
+                out["config"]["c4_strong"] = c4_leg
+            # the same with two frames in flight (--in-flight 2): a rank's part of ONE frame is 5 waves per slot at N = 8 and ends in a
+            # tail of its dearest tiles (one 8x8 tile = one wave, up to 5x the mean); the next frame's first waves fill that tail
+            del c4_tiler
+            _, c4_tiler, _, c4_dt2, c4_rays2, _, _ = measure(c4_hs, "strong", "rank0", c4_steps, c4_warm, False, 2)
+            c4_leg["frame_ms_two_in_flight"] = c4_dt2 / c4_steps * 1e3
+            c4_leg["mrays_per_s_two_in_flight"] = c4_rays2 * c4_steps / c4_dt2 / 1e6
+            if world == 1:
+                c4_ds = ca.DeviceScene(c4_hs, device=local_rank)
+                c4_ds.set_variant(ca.VAR_STATS)
+                ca.DeviceScene.lane_stats(reset=True)
+                c4_ds.render(bounces=args.bounces)
+                c4_leg["live_lanes"] = _live_summary(ca.DeviceScene.lane_stats(reset=True))
+                c4_ds.close()
+            del c4_tiler
+        if not args.no_extras and args.in_flight == 1 and not sim:
+            # the timed workload once more with two steps in flight (--in-flight 2), untimed for `value`
+            _, t2_tiler, _, t2_dt, t2_rays, _, _ = measure(hs, args.scaling, args.roots, args.steps, args.warmup, False, 2)
+            if rank == 0:
+                out["config"]["two_steps_in_flight"] = {
+                    "ms_per_step": t2_dt / args.steps * 1e3, "mrays_per_s": t2_rays * args.steps / t2_dt / 1e6,
+                    "what": "consecutive steps alternate between two scene handles on two streams: the first waves of step k+1 fill the "
+                            "slots the tail of step k leaves empty; `value` above is measured with one launch after the other"}
+            del t2_tiler
         if rank == 0:
-            out["config"]["c4_strong"] = c4_leg
-        # the same with two frames in flight (--in-flight 2): a rank's part of ONE frame is 5 waves per slot at N = 8 and ends in a
-        # tail of its dearest tiles (one 8x8 tile = one wave, up to 5x the mean); the next frame's first waves fill that tail
-        del c4_tiler
-        _, c4_tiler, _, c4_dt2, c4_rays2, _, _ = measure(c4_hs, "strong", "rank0", c4_steps, c4_warm, False, 2)
-        c4_leg["frame_ms_two_in_flight"] = c4_dt2 / c4_steps * 1e3
-        c4_leg["mrays_per_s_two_in_flight"] = c4_rays2 * c4_steps / c4_dt2 / 1e6
-        if world == 1:
-            c4_ds = ca.DeviceScene(c4_hs, device=local_rank)
-            c4_ds.set_variant(ca.VAR_STATS)
-            ca.DeviceScene.lane_stats(reset=True)
-            c4_ds.render(bounces=args.bounces)
-            c4_leg["live_lanes"] = _live_summary(ca.DeviceScene.lane_stats(reset=True))
-            c4_ds.close()
-        del c4_tiler
-    if not args.no_extras and args.in_flight == 1 and not sim:
-        # the timed workload once more with two steps in flight (--in-flight 2), untimed for `value`
-        _, t2_tiler, _, t2_dt, t2_rays, _, _ = measure(hs, args.scaling, args.roots, args.steps, args.warmup, False, 2)
-        if rank == 0:
-            out["config"]["two_steps_in_flight"] = {
-                "ms_per_step": t2_dt / args.steps * 1e3, "mrays_per_s": t2_rays * args.steps / t2_dt / 1e6,
-                "what": "consecutive steps alternate between two scene handles on two streams: the first waves of step k+1 fill the "
-                        "slots the tail of step k leaves empty; `value` above is measured with one launch after the other"}
-        del t2_tiler
-    if rank == 0:
-        if world == 1 and not args.no_extras:
-            out["config"].update(extras(ca, hs, args, ds))
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ca, hs, args.bounces, args.cpu_sample_div)
+            if world == 1 and not args.no_extras:
+                out["config"].update(extras(ca, hs, args, ds))
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(ca, hs, args.bounces, args.cpu_sample_div)
+    except Exception as e:  # noqa: BLE001 — whatever goes wrong in a side measurement must not cost the timed result
+        import traceback
+        traceback.print_exc()
+        emit_and_leave(f"a side measurement failed on rank {rank}: {type(e).__name__}: {e}")
     watchdog.cancel()
     if printed.acquire(blocking=False):
         if rank == 0:
