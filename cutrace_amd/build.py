@@ -27,7 +27,7 @@ HIP_SRCS = [os.path.join(CSRC, "render_kernel.hip"), os.path.join(CSRC, "ctr_api
             os.path.join(CSRC, "ctr_multi.hip")]
 CLI_SRCS = [os.path.join(HOST, "main.cpp")]
 
-HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-I" + INC]
+HOST_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-pthread", "-Wall", "-I" + INC]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC",
     "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics",
@@ -81,7 +81,7 @@ def build_cli(force=False):
     build_host(force)
     build_hip(force)
     if force or not _newer(CLI, CLI_SRCS + [HOST_LIB, HIP_LIB]):
-        _run([hipcc(), "-std=c++17", "-O2", "-ffp-contract=off", "-I" + INC, "-I" + HOST, "-o", CLI, *CLI_SRCS,
+        _run([hipcc(), "-std=c++17", "-O2", "-ffp-contract=off", "-pthread", "-I" + INC, "-I" + HOST, "-o", CLI, *CLI_SRCS,
               "-L" + PKG, "-lcutrace_amd", "-lcutrace_host", "-Wl,-rpath,$ORIGIN"])
     return CLI
 

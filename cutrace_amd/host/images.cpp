@@ -14,6 +14,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../../include/cutrace_host.h"
@@ -100,15 +103,20 @@ struct bitwriter {
   }
 };
 
-void fdct8x8(const float *in, float *out) {
-  // separable direct DCT-II (clarity over speed: the writer is off the hot path)
-  static float C[8][8];
-  static bool init = false;
-  if (!init) {
+// the DCT basis, built once (a function-local static object: its construction is thread-safe — the three images of a frame
+// are written by three threads, and each writer transforms its blocks on several more)
+struct DctBasis {
+  float C[8][8];
+  DctBasis() {
     for (int u = 0; u < 8; u++)
       for (int x = 0; x < 8; x++) C[u][x] = (float)((u == 0 ? sqrt(0.125) : 0.5) * cos((2 * x + 1) * u * M_PI / 16.0));
-    init = true;
   }
+};
+
+void fdct8x8(const float *in, float *out) {
+  // separable direct DCT-II (clarity over speed; the speed comes from doing the blocks in parallel)
+  static const DctBasis B;
+  const float (*C)[8] = B.C;
   float tmp[64];
   for (int y = 0; y < 8; y++)
     for (int u = 0; u < 8; u++) {
@@ -127,14 +135,19 @@ void fdct8x8(const float *in, float *out) {
 void put_marker(std::vector<byte> &o, byte m) { o.push_back(0xFF); o.push_back(m); }
 void put16(std::vector<byte> &o, unsigned v) { o.push_back((byte)(v >> 8)); o.push_back((byte)(v & 0xFF)); }
 
-void encode_block(bitwriter &bw, const float *blk, const byte *q, int &dc_prev, const huff &dc, const huff &ac) {
+// A block in two steps, so that the first — transform and quantisation, independent from block to block and most of the
+// work — can run on several threads, while the second — entropy coding, where every block's DC value is predicted from the
+// previous block's and the bits are packed one after the other — runs in order afterwards.  Same arithmetic as one step.
+void quantise_block(const float *blk, const byte *q, short *z) {
   float f[64];
   fdct8x8(blk, f);
-  int z[64];
   for (int i = 0; i < 64; i++) {
     float v = f[ZIGZAG[i]] / (float)q[ZIGZAG[i]];
-    z[i] = (int)(v < 0 ? v - 0.5f : v + 0.5f);
+    z[i] = (short)(int)(v < 0 ? v - 0.5f : v + 0.5f);
   }
+}
+
+void entropy_block(bitwriter &bw, const short *z, int &dc_prev, const huff &dc, const huff &ac) {
   auto magnitude = [](int v, int &bits) {
     int a = v < 0 ? -v : v, n = 0;
     while (a) { n++; a >>= 1; }
@@ -238,24 +251,47 @@ int ctr_write_jpg(const char *path, int w, int h, const unsigned char *rgb, int 
   huff hdl, hal, hdc, hac;
   hdl.build(DC_L_BITS, DC_L_VAL); hal.build(AC_L_BITS, AC_L_VAL);
   hdc.build(DC_C_BITS, DC_C_VAL); hac.build(AC_C_BITS, AC_C_VAL);
+  // step 1, in parallel over the rows of blocks: colour transform, DCT, quantisation -> 3 x 64 coefficients per block
+  const int nbx = (w + 7) / 8, nby = (h + 7) / 8;
+  std::vector<short> coef((size_t)nbx * nby * 3 * 64);
+  auto rows = [&](int first, int step) {
+    float Y[64], Cb[64], Cr[64];
+    for (int br = first; br < nby; br += step)
+      for (int bc = 0; bc < nbx; bc++) {
+        const int by = br * 8, bx = bc * 8;
+        for (int yy = 0; yy < 8; yy++)
+          for (int xx = 0; xx < 8; xx++) {
+            int y = by + yy < h ? by + yy : h - 1, x = bx + xx < w ? bx + xx : w - 1;
+            const byte *p = rgb + 3 * ((size_t)y * w + x);
+            float r = p[0], g = p[1], b = p[2];
+            Y[yy * 8 + xx] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
+            Cb[yy * 8 + xx] = -0.168736f * r - 0.331264f * g + 0.5f * b;
+            Cr[yy * 8 + xx] = 0.5f * r - 0.418688f * g - 0.081312f * b;
+          }
+        short *z = &coef[((size_t)br * nbx + bc) * 3 * 64];
+        quantise_block(Y, ql, z);
+        quantise_block(Cb, qc, z + 64);
+        quantise_block(Cr, qc, z + 128);
+      }
+  };
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("CUTRACE_JPEG_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+    const int T = std::max(1, std::min({(int)(hw ? hw : 1u), 16, nby / 4 + 1}));
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(rows, t, T);
+    rows(0, T);
+    for (std::thread &x : th) x.join();
+  }
+  // step 2, in order: entropy coding
   bitwriter bw(o);
   int dcy = 0, dcb = 0, dcr = 0;
-  float Y[64], Cb[64], Cr[64];
-  for (int by = 0; by < h; by += 8)
-    for (int bx = 0; bx < w; bx += 8) {
-      for (int yy = 0; yy < 8; yy++)
-        for (int xx = 0; xx < 8; xx++) {
-          int y = by + yy < h ? by + yy : h - 1, x = bx + xx < w ? bx + xx : w - 1;
-          const byte *p = rgb + 3 * ((size_t)y * w + x);
-          float r = p[0], g = p[1], b = p[2];
-          Y[yy * 8 + xx] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
-          Cb[yy * 8 + xx] = -0.168736f * r - 0.331264f * g + 0.5f * b;
-          Cr[yy * 8 + xx] = 0.5f * r - 0.418688f * g - 0.081312f * b;
-        }
-      encode_block(bw, Y, ql, dcy, hdl, hal);
-      encode_block(bw, Cb, qc, dcb, hdc, hac);
-      encode_block(bw, Cr, qc, dcr, hdc, hac);
-    }
+  for (size_t k = 0; k < (size_t)nbx * nby; k++) {
+    const short *z = &coef[k * 3 * 64];
+    entropy_block(bw, z, dcy, hdl, hal);
+    entropy_block(bw, z + 64, dcb, hdc, hac);
+    entropy_block(bw, z + 128, dcr, hdc, hac);
+  }
   bw.flush();
   put_marker(o, 0xD9);
   FILE *f = fopen(path, "wb");

@@ -9,6 +9,7 @@
 //                       gather to GPU 0, same three files); CUTRACE_DEVICE_LIST=0,2,... names them instead
 #include <cstdlib>
 #include <iostream>
+#include <thread>
 #include <vector>
 
 #include "cutrace_amd.h"
@@ -19,6 +20,18 @@
 static long env_long(const char *name, long def) {
   const char *v = getenv(name);
   return (v && *v) ? atol(v) : def;
+}
+
+// the three output files of main.cu:34-41 (inc/images.hpp:26-88), written at the same time: they are independent, and a 1080p JPEG is
+// 10-45 ms of host work each (138 ms one after the other with a single-threaded encoder, 15 ms now: scripts/cpu_jpeg_time.py) in a
+// process whose render call takes 13
+static void write_images(cutrace::grid<float> &depth_map, cutrace::grid<cutrace::vector> &color_map,
+                         cutrace::grid<cutrace::vector> &normal_map, float max_d) {
+  std::thread t_depth([&] { ctr_write_depth_map("./depth_map.jpg", depth_map.data(), depth_map.cols(), depth_map.rows(), max_d); });
+  std::thread t_normal([&] { ctr_write_normal_map("./normal_map.jpg", &normal_map.data()->x, normal_map.cols(), normal_map.rows()); });
+  ctr_write_colorized("./frame.jpg", &color_map.data()->x, color_map.cols(), color_map.rows());
+  t_depth.join();
+  t_normal.join();
 }
 
 int main(int argc, const char **argv) {
@@ -68,9 +81,7 @@ int main(int argc, const char **argv) {
     cutrace::gpu::render_multi(group, (size_t)env_long("CUTRACE_BOUNCES", 5), 1e-3, max_d, depth_map, color_map, normal_map,
                                render, total);
     std::cout << "Render time was " << render << " ms; kernel time with setup/teardown was " << total << " ms.\n";
-    ctr_write_depth_map("./depth_map.jpg", depth_map.data(), depth_map.cols(), depth_map.rows(), max_d);
-    ctr_write_normal_map("./normal_map.jpg", &normal_map.data()->x, normal_map.cols(), normal_map.rows());
-    ctr_write_colorized("./frame.jpg", &color_map.data()->x, color_map.cols(), color_map.rows());
+    write_images(depth_map, color_map, normal_map, max_d);
     ctr_multi_destroy(group);
     ctr_host_scene_free(hs);
     return 0;
@@ -96,9 +107,7 @@ int main(int argc, const char **argv) {
 
   std::cout << "Render time was " << render << " ms; kernel time with setup/teardown was " << total << " ms.\n";
 
-  ctr_write_depth_map("./depth_map.jpg", depth_map.data(), depth_map.cols(), depth_map.rows(), max_d);
-  ctr_write_normal_map("./normal_map.jpg", &normal_map.data()->x, normal_map.cols(), normal_map.rows());
-  ctr_write_colorized("./frame.jpg", &color_map.data()->x, color_map.cols(), color_map.rows());
+  write_images(depth_map, color_map, normal_map, max_d);
 
   ctr_scene_destroy(scene);
   ctr_host_scene_free(hs);

@@ -5,7 +5,7 @@ set -e
 OUT=${TMPDIR:-/tmp}/ctr_san
 mkdir -p $OUT
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1"
-g++ -std=c++17 -ffp-contract=off -fPIC -Wall -Iinclude $SAN -shared -o $OUT/libcutrace_host_san.so cutrace_amd/host/scene_host.cpp cutrace_amd/host/images.cpp
+g++ -std=c++17 -ffp-contract=off -fPIC -pthread -Wall -Iinclude $SAN -shared -o $OUT/libcutrace_host_san.so cutrace_amd/host/scene_host.cpp cutrace_amd/host/images.cpp
 gcc -ffp-contract=off -fPIC -Wall -Wno-unused-function -pthread $SAN -shared -o $OUT/libctr_oracle_san.so oracle/ctr_oracle.c -lm
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1
