@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -735,6 +736,40 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
   std::vector<ctr_scene::MeshGuard> guards;
   tris.reserve(d->n_triangles + d->n_objects);
   bool has_mesh = false;
+  // the meshes' trees first, several meshes at a time (a scene of 16 meshes of 1000 triangles: 2.5 -> 0.5 ms of this call; a mesh
+  // large enough to matter is built on several threads by the builder itself)
+  struct MeshTree { std::vector<DNode4> nodes; std::vector<uint32_t> order; };
+  std::vector<MeshTree> trees(d->n_objects);
+  {
+    std::vector<uint64_t> mesh_ids;
+    for (uint64_t i = 0; i < d->n_objects; i++)
+      if (d->objects[i].type == CTR_OBJ_MESH && d->objects[i].tri_count <= 0xFFFFFFull) mesh_ids.push_back(i);
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+      for (size_t k; (k = next.fetch_add(1)) < mesh_ids.size();) {
+        const ctr_object &o = d->objects[mesh_ids[k]];
+        const ctr_triangle *src = d->triangles + o.tri_begin;
+        const uint32_t n = (uint32_t)o.tri_count;
+        std::vector<BvhInput> prims(n);
+        for (uint32_t q = 0; q < n; q++) {
+          const ctr_vec3 *v[3] = {&src[q].p1, &src[q].p2, &src[q].p3};
+          BvhInput &b = prims[q];
+          for (int a = 0; a < 3; a++) {
+            const float c0 = (&v[0]->x)[a], c1 = (&v[1]->x)[a], c2 = (&v[2]->x)[a];
+            b.mn[a] = fminf(c0, fminf(c1, c2));
+            b.mx[a] = fmaxf(c0, fmaxf(c1, c2));
+            b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
+          }
+        }
+        bvh4_build(prims, BVH_LEAF, trees[mesh_ids[k]].nodes, trees[mesh_ids[k]].order);
+      }
+    };
+    const size_t n_thr = std::min<size_t>(mesh_ids.size() > 1 ? mesh_ids.size() : 1, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_thr; t++) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+  }
   for (uint64_t i = 0; i < d->n_objects; i++) {
     const ctr_object &o = d->objects[i];
     DObj &O = objs[i];
@@ -761,21 +796,9 @@ int ctr_scene_create(const ctr_scene_desc *d, int device, ctr_scene **out) {
         has_mesh = true;
         const ctr_triangle *src = d->triangles + o.tri_begin;
         const uint32_t n = (uint32_t)o.tri_count;
-        std::vector<BvhInput> prims(n);
-        for (uint32_t k = 0; k < n; k++) {
-          const ctr_vec3 *v[3] = {&src[k].p1, &src[k].p2, &src[k].p3};
-          BvhInput &b = prims[k];
-          for (int a = 0; a < 3; a++) {
-            const float c0 = (&v[0]->x)[a], c1 = (&v[1]->x)[a], c2 = (&v[2]->x)[a];
-            b.mn[a] = fminf(c0, fminf(c1, c2));
-            b.mx[a] = fmaxf(c0, fmaxf(c1, c2));
-            b.c[a] = 0.5f * (b.mn[a] + b.mx[a]);
-          }
-        }
-        if (n > 0xFFFFFFu) return fail(CTR_E_INVALID, "object #" + std::to_string(i) + ": mesh has more than 2^24 triangles");
-        std::vector<DNode4> mnodes;
-        std::vector<uint32_t> order;
-        bvh4_build(prims, BVH_LEAF, mnodes, order);
+        if (o.tri_count > 0xFFFFFFull) return fail(CTR_E_INVALID, "object #" + std::to_string(i) + ": mesh has more than 2^24 triangles");
+        std::vector<DNode4> &mnodes = trees[i].nodes;
+        std::vector<uint32_t> &order = trees[i].order;
         O.tri_begin = (uint32_t)tris.size();
         O.tri_count = n;
         O.node_begin = (uint32_t)nodes4.size();
