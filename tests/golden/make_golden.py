@@ -69,6 +69,17 @@ def main():
     np.savez_compressed(path, depth=r["depth"], color=r["color"], normal=r["normal"], uv=r["uv"], hit_id=r["hit_id"].astype(np.int32),
                         ray_count=np.int64(r["ray_count"]))
     print("wrote", path)
+    # ... and at the full 1920x1080 (samples + checksums, like the full_* fixtures)
+    if "--no-full-ign" not in sys.argv:
+        s = ca.HostScene.load("scene/sphere_plane.json")
+        r = oracle.ref_render(s, bounces=5, threads=THREADS, uv=True, ignore_transparent_primary=True)
+        w, h = s.size
+        idx = np.sort(np.random.RandomState(4321).choice(w * h, 4096, replace=False)).astype(np.int64)
+        path = os.path.join(OUT, f"full_ignore_transparent_sphere_plane_{w}x{h}_b5.npz")
+        np.savez_compressed(path, sample_idx=idx, depth=r["depth"].reshape(-1)[idx], color=r["color"].reshape(-1, 3)[idx],
+                            normal=r["normal"].reshape(-1, 3)[idx], uv=r["uv"].reshape(-1, 2)[idx], hit_id=r["hit_id"].reshape(-1)[idx].astype(np.int32),
+                            **sums(r))
+        print("wrote", path, sums(r))
     if "--uv-only" in sys.argv:
         return
     only_small = "--small" in sys.argv

@@ -874,3 +874,25 @@ def test_ignore_transparent_primary_cast(ca):
         assert_parity(got, o, what=f"ignore_transparent seed {seed}")
         assert got["ray_count"] == o["ray_count"]
         x.close()
+
+
+def test_ignore_transparent_full_resolution_against_golden_samples(ca):
+    """CTR_VAR_IGNORE_TRANSPARENT at BASELINE's full size (sphere_plane.json @1920x1080) against 4096 sampled pixels and the checksums of the
+    frame the reference build rendered with its ray_cast called with `true`: depth / normal bit-exact, uv within 1e-4, colour within 1e-4 (and
+    bit-equal to the plain render's: ray_color's own casts pass false)."""
+    g = np.load(os.path.join(GOLD, "full_ignore_transparent_sphere_plane_1920x1080_b5.npz"))
+    s = load_scene(ca, "sphere_plane")
+    ds = ca.DeviceScene(s)
+    plain = ds.render(bounces=5)
+    ds.set_variant(ca.VAR_IGNORE_TRANSPARENT)
+    r = ds.render_uv(bounces=5)
+    idx = g["sample_idx"]
+    assert same_bits(r["depth"].reshape(-1)[idx], g["depth"]) and same_bits(r["normal"].reshape(-1, 3)[idx], g["normal"])
+    assert np.abs(r["color"].reshape(-1, 3)[idx].astype(np.float64) - g["color"].astype(np.float64)).max() <= 1e-4
+    assert _uv_close(r["uv"].reshape(-1, 2)[idx], g["uv"])
+    assert same_bits(r["color"], plain["color"]) and r["ray_count"] == int(g["ray_count"]) == 13973091
+    fin = np.isfinite(r["depth"])
+    assert int(fin.sum()) == int(g["n_finite"])
+    assert abs(float(r["depth"][fin].astype(np.float64).sum()) - float(g["sum_depth"])) < 1e-6 * abs(float(g["sum_depth"]))
+    assert int((r["depth"].view(np.uint32) != plain["depth"].view(np.uint32)).sum()) > 100000   # the glass sphere is gone from the depth map
+    ds.close()

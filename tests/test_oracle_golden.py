@@ -254,3 +254,15 @@ def test_oracle_ignore_transparent_matches_reference_fixture(ca):
         live = oracle.ref_render(s, bounces=5, threads=4, uv=True, ignore_transparent_primary=True)
         for k in ("depth", "normal", "color", "uv"):
             assert same_bits(r[k], live[k]), k
+
+
+def test_oracle_ignore_transparent_full_resolution_samples(ca):
+    """The same branch at BASELINE's full size: sphere_plane.json @1920x1080, the kernel.hpp:52 cast with ignore_transparent = true — 4096 sampled
+    pixels and the checksums of a frame the reference build rendered (its ray_cast called with `true`)."""
+    g = np.load(os.path.join(GOLD, "full_ignore_transparent_sphere_plane_1920x1080_b5.npz"))
+    s = load_scene(ca, "sphere_plane")
+    r = oracle.oracle_render(s, bounces=5, threads=os.cpu_count() or 4, uv=True, ignore_transparent_primary=True)
+    idx = g["sample_idx"]
+    for k, n in (("depth", 1), ("color", 3), ("normal", 3), ("uv", 2)):
+        assert same_bits(r[k].reshape(-1, n)[idx] if n > 1 else r[k].reshape(-1)[idx], g[k]), k
+    assert r["ray_count"] == int(g["ray_count"]) == 13973091 and int(np.isfinite(r["depth"]).sum()) == int(g["n_finite"])
