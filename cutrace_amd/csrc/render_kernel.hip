@@ -887,21 +887,20 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             //  the one it wants after the test — a second dependent round trip per node)
             uint32_t n_left = N.left, n_right = N.right;
             asm volatile("" : "+s"(n_left), "+s"(n_right));
-            // (which children are hit as two bits of a scalar integer: as `bool`s picked by another bool the compiler sends
-            //  them through a VGPR and back — two v_cndmask and two v_readfirstlane per node)
-            const uint32_t c0 = (uint32_t)__builtin_popcountll(t_hits(0)), c1 = (uint32_t)__builtin_popcountll(t_hits(1));
-            const uint32_t hit01 = (c0 < 1u ? c0 : 1u) | ((c1 < 1u ? c1 : 1u) << 1);  // (umin: no boolean anywhere)
-            const uint32_t hit = t_rev ? (((hit01 & 1u) << 1) | (hit01 >> 1)) : hit01;  // bit 0: the nearer child, bit 1: the farther
-            const uint32_t dl = t_rev ? n_right : n_left, dr = t_rev ? n_left : n_right;
-            if (hit == 3u) {
-              t_stack_v = ctr_writelane(__builtin_amdgcn_readfirstlane(dr),
-                                                       __builtin_amdgcn_readfirstlane(t_sp), t_stack_v);
-              t_sp++;
-              t_pend = dl;
-            } else if (hit == 1u) {
-              t_pend = dl;
-            } else if (hit == 2u) {
-              t_pend = dr;
+            // The two hit masks stay lane masks and the four cases are told apart by comparing them with zero (round 4: the
+            // earlier form — hit counts folded into two bits of an integer, swapped by `t_rev`, then a chain of four equality
+            // tests — cost 47 scalar instructions and 15 branches per node; this one about half of that).
+            const mask_t tm0 = t_hits(0), tm1 = t_hits(1);
+            const mask_t mN = t_rev ? tm1 : tm0, mF = t_rev ? tm0 : tm1;   // the nearer / the farther child along the lead ray
+            const uint32_t dN = t_rev ? n_right : n_left, dF = t_rev ? n_left : n_right;
+            if (mN != 0ull) {
+              if (mF != 0ull) {
+                t_stack_v = ctr_writelane(__builtin_amdgcn_readfirstlane(dF), __builtin_amdgcn_readfirstlane(t_sp), t_stack_v);
+                t_sp++;
+              }
+              t_pend = dN;
+            } else if (mF != 0ull) {
+              t_pend = dF;
             } else if (t_sp != 0u) {
               t_sp--;
               t_pend = (uint32_t)__builtin_amdgcn_readlane((int)t_stack_v, (int)t_sp);
@@ -1197,25 +1196,41 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             // children (c, c+1) of one node: six v_pk_fma_f32 give the six slab distances of both boxes;
             // a lane takes a child unless it misses for certain: max(entry, min_t) > min(exit, lim)
             // (v_min/v_max drop a NaN operand, a NaN that survives compares false -> entered)
-            auto box_hits2 = [&](const CADDR DNode4 &N, int c, mask_t &ha, mask_t &hb) {
+            auto box_hits2 = [&](const auto &N, int c, mask_t &ha, mask_t &hb) {
               float2_ t1x, t1y, t1z, t2x, t2y, t2z;
-              PKFMA(t1x, ldpair2(&N.lo[0][c]), c_rxy, 0, c_rzk, 1);
-              PKFMA(t1y, ldpair2(&N.lo[1][c]), c_rxy, 1, c_kyz, 0);
-              PKFMA(t1z, ldpair2(&N.lo[2][c]), c_rzk, 0, c_kyz, 1);
-              PKFMA(t2x, ldpair2(&N.hi[0][c]), c_rxy, 0, c_bxy, 0);
-              PKFMA(t2y, ldpair2(&N.hi[1][c]), c_rxy, 1, c_bxy, 1);
-              PKFMA(t2z, ldpair2(&N.hi[2][c]), c_rzk, 0, c_bz, 0);
-              const float lo_a = slab_lo4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, min_t);
-              const float hi_a = slab_hi4(t1x.x, t2x.x, t1y.x, t2y.x, t1z.x, t2z.x, lim);
-              const float lo_b = slab_lo4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, min_t);
-              const float hi_b = slab_hi4(t1x.y, t2x.y, t1y.y, t2y.y, t1z.y, t2z.y, lim);
-              ha = bb_m & ~FCMP(lo_a, hi_a, FC_OGT);
-              hb = bb_m & ~FCMP(lo_b, hi_b, FC_OGT);
+              PKFMA(t1x, (float2_{N.lo[0][c], N.lo[0][c + 1]}), c_rxy, 0, c_rzk, 1);
+              PKFMA(t1y, (float2_{N.lo[1][c], N.lo[1][c + 1]}), c_rxy, 1, c_kyz, 0);
+              PKFMA(t1z, (float2_{N.lo[2][c], N.lo[2][c + 1]}), c_rzk, 0, c_kyz, 1);
+              PKFMA(t2x, (float2_{N.hi[0][c], N.hi[0][c + 1]}), c_rxy, 0, c_bxy, 0);
+              PKFMA(t2y, (float2_{N.hi[1][c], N.hi[1][c + 1]}), c_rxy, 1, c_bxy, 1);
+              PKFMA(t2z, (float2_{N.hi[2][c], N.hi[2][c + 1]}), c_rzk, 0, c_bz, 0);
+              // both boxes' slab arithmetic as ONE statement (the same twenty-two instructions, interleaved): between separate
+              // statements the compiler pads with s_nop for hazards it cannot rule out — eleven per node visit
+              float u0, u1, u2, u3, w0, w1, w2, w3;
+              mask_t ma, mb;
+              asm("v_min_f32 %0, %10, %13\n\tv_min_f32 %4, %16, %19\n\t"
+                  "v_min_f32 %1, %11, %14\n\tv_min_f32 %5, %17, %20\n\t"
+                  "v_min_f32 %2, %12, %15\n\tv_min_f32 %6, %18, %21\n\t"
+                  "v_max_f32 %3, %10, %13\n\tv_max_f32 %7, %16, %19\n\t"
+                  "v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %4, %4, %5, %6\n\t"
+                  "v_max_f32 %1, %11, %14\n\tv_max_f32 %5, %17, %20\n\t"
+                  "v_max_f32 %2, %12, %15\n\tv_max_f32 %6, %18, %21\n\t"
+                  "v_max_f32 %0, %0, %22\n\tv_max_f32 %4, %4, %22\n\t"
+                  "v_min3_f32 %1, %3, %1, %2\n\tv_min3_f32 %5, %7, %5, %6\n\t"
+                  "v_min_f32 %1, %1, %23\n\tv_min_f32 %5, %5, %23\n\t"
+                  "v_cmp_gt_f32_e64 %8, %0, %1\n\tv_cmp_gt_f32_e64 %9, %4, %5"
+                  : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&s"(ma), "=&s"(mb)
+                  : "v"(t1x.x), "v"(t1y.x), "v"(t1z.x), "v"(t2x.x), "v"(t2y.x), "v"(t2z.x),
+                    "v"(t1x.y), "v"(t1y.y), "v"(t1z.y), "v"(t2x.y), "v"(t2y.y), "v"(t2z.y), "v"(min_t), "v"(lim));
+              ha = bb_m & ~ma;
+              hb = bb_m & ~mb;
             };
+            const CADDR DTri *tb_ = A.tris + beg;   // the mesh's first record: leaves address theirs by a 32-bit byte offset from it
             auto leaf = [&](uint32_t desc, mask_t lanes) {
               TSTAMP(t_leaf0);
               CTR_MARK(80);  // a leaf's triangles
-              const uint32_t first = beg + (desc & 0xFFFFFFu), n_l = (desc >> 24) & 0x7Fu;
+              uint32_t t_off = (desc & 0xFFFFFFu) << 6;   // byte offset of the leaf's first record from the mesh's first
+              const uint32_t n_l = (desc >> 24) & 0x7Fu;
               // The leaf's first triangle is fetched as one 64-byte record, and one dword of each of the next three cache
               // lines is requested with it, into a register nobody reads ("touch"): the loads of the leaf's other triangles —
               // one dependent round trip each — then find their lines in the scalar cache.  64 000 triangles -3 %, first
@@ -1228,21 +1243,27 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               typedef uint32_t u32x16_ __attribute__((ext_vector_type(16)));
               u32x16_ t0;
               uint32_t touch_;
-              asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_load_dword %1, %2, 0x80\n\ts_load_dword %1, %2, 0xc0\n\ts_waitcnt lgkmcnt(0)"
-                           : "=&s"(t0), "=&s"(touch_) : "s"(&A.tris[first]));
+              asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dword %1, %2, %3 offset:0x40\n\ts_load_dword %1, %2, %3 offset:0x80\n\ts_load_dword %1, %2, %3 offset:0xc0\n\ts_waitcnt lgkmcnt(0)"
+                           : "=&s"(t0), "=&s"(touch_) : "s"(tb_), "s"(t_off));
               TriR cur;
-              cur.ab0.x = __uint_as_float(t0[0]); cur.ab0.y = __uint_as_float(t0[1]); cur.ab1.x = __uint_as_float(t0[2]); cur.ab1.y = __uint_as_float(t0[3]);
-              cur.ab2.x = __uint_as_float(t0[4]); cur.ab2.y = __uint_as_float(t0[5]); cur.pxy.x = __uint_as_float(t0[6]); cur.pxy.y = __uint_as_float(t0[7]);
-              cur.pz = __uint_as_float(t0[8]); cur.orig = t0[9]; cur.nx = __uint_as_float(t0[10]); cur.ny = __uint_as_float(t0[11]);
+#define CTR_UNPACK_TRI()                                                                                                                              \
+              cur.ab0.x = __uint_as_float(t0[0]); cur.ab0.y = __uint_as_float(t0[1]); cur.ab1.x = __uint_as_float(t0[2]); cur.ab1.y = __uint_as_float(t0[3]); \
+              cur.ab2.x = __uint_as_float(t0[4]); cur.ab2.y = __uint_as_float(t0[5]); cur.pxy.x = __uint_as_float(t0[6]); cur.pxy.y = __uint_as_float(t0[7]); \
+              cur.pz = __uint_as_float(t0[8]); cur.orig = t0[9]; cur.nx = __uint_as_float(t0[10]); cur.ny = __uint_as_float(t0[11]);                       \
               cur.nz = __uint_as_float(t0[12]); cur.ke = __uint_as_float(t0[13]); cur.ke2 = __uint_as_float(t0[14]);
+              CTR_UNPACK_TRI()
               for (uint32_t k = 0;;) {
-                tri_test(cur, first + k, lanes & bb_m);
+                tri_test(cur, 0u, lanes & bb_m);
                 if (ANYHIT) {
                   if (bb_m == 0ull) break;
                 }
                 if (++k >= n_l) break;
                 CTR_MARK(82);  // the leaf's next triangle
-                cur = load_tri(A.tris[first + k]);
+                // the leaf's next record: ONE 64-byte request at the running offset (the compiler's own form is a 64-bit address
+                // and four requests for the record's fifteen words)
+                t_off += 64u;
+                asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0) : "s"(tb_), "s"(t_off));
+                CTR_UNPACK_TRI()
               }
 #ifdef CTR_TIMING
               t_leaves += __builtin_readcyclecounter() - t_leaf0;
@@ -1266,7 +1287,18 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
             for (;;) {
               if (STATS) st[1]++;
               CTR_MARK(32);  // BVH node
-              const CADDR DNode4 &N = nodes4[cur];
+              // the node's 128 bytes as two requests at a 32-bit byte offset from the mesh's first node (one shift; the compiler's
+              // own form was a 64-bit address — four scalar instructions — and five requests in three waits)
+              typedef uint32_t u32x16n_ __attribute__((ext_vector_type(16)));
+              u32x16n_ nq0, nq1;
+              asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %3 offset:0x40\n\ts_waitcnt lgkmcnt(0)"
+                           : "=&s"(nq0), "=&s"(nq1) : "s"(nodes4), "s"(cur << 7));
+              struct NodeR { float lo[3][4], hi[3][4]; uint32_t child[4], axis; } N;
+              for (int a_ = 0; a_ < 3; ++a_) for (int c_ = 0; c_ < 4; ++c_) N.lo[a_][c_] = __uint_as_float(nq0[a_ * 4 + c_]);
+              for (int c_ = 0; c_ < 4; ++c_) N.hi[0][c_] = __uint_as_float(nq0[12 + c_]);
+              for (int a_ = 1; a_ < 3; ++a_) for (int c_ = 0; c_ < 4; ++c_) N.hi[a_][c_] = __uint_as_float(nq1[(a_ - 1) * 4 + c_]);
+              for (int c_ = 0; c_ < 4; ++c_) N.child[c_] = nq1[8 + c_];
+              N.axis = nq1[12];
               mask_t h0, h1, h2, h3;
               box_hits2(N, 0, h0, h1);
               box_hits2(N, 2, h2, h3);
@@ -1276,10 +1308,10 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
               const uint32_t d0 = N.child[0], d1 = N.child[1], d2 = N.child[2], d3 = N.child[3], n_axis_ = N.axis;
               if (STATS) { st[6] += __builtin_popcountll(h0 | h1 | h2 | h3); pl_nodes += INVB(h0 | h1 | h2 | h3) ? 1u : 0u; }
               // children are stored sorted along the node's order axis; a wave whose lead ray points the other
-              // way takes them in reverse (wave-uniform selects): e0/g0 = nearest ... e3/g3 = farthest
+              // way takes them in reverse: TWO copies of the dispatch below behind one scalar branch — selecting the four
+              // descriptors and four masks into "nearest ... farthest" registers first was ten scalar instructions per visit
+              // (round 4: bunny -3.4 %, 64 000 triangles -2.7 %; profiles/r04/exp_scalar_diet_ab.txt)
               const bool rev = ((neg_bits >> n_axis_) & 1u) != 0u;
-              const uint32_t e0 = rev ? d3 : d0, e1 = rev ? d2 : d1, e2 = rev ? d1 : d2, e3 = rev ? d0 : d3;
-              const mask_t g0 = rev ? h3 : h0, g1 = rev ? h2 : h1, g2 = rev ? h1 : h2, g3 = rev ? h0 : h3;
               // ONE pass, farthest child first: a hit leaf is tested at once; a hit inner child becomes the node to
               // visit next and whatever was to be visited next is pushed — so the nearest inner child is visited
               // next and the stack pops nearest-first.  No per-child bookkeeping beyond two scalar tests.
@@ -1302,10 +1334,17 @@ __global__ __launch_bounds__(WG_THREADS, (KV & KV_OCC6) ? 6 : CTR_MIN_WAVES_EU) 
       next = (e);                                                   \
     }                                                               \
   }
-              CTR_CHILD(e3, g3, 60)
-              CTR_CHILD(e2, g2, 61)
-              CTR_CHILD(e1, g1, 62)
-              CTR_CHILD(e0, g0, 63)
+              if (rev) {
+                CTR_CHILD(d0, h0, 60)
+                CTR_CHILD(d1, h1, 61)
+                CTR_CHILD(d2, h2, 62)
+                CTR_CHILD(d3, h3, 63)
+              } else {
+                CTR_CHILD(d3, h3, 60)
+                CTR_CHILD(d2, h2, 61)
+                CTR_CHILD(d1, h1, 62)
+                CTR_CHILD(d0, h0, 63)
+              }
 #undef CTR_CHILD
               CTR_MARK(34);
               if (done) break;
